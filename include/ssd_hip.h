@@ -1,0 +1,218 @@
+/*
+ * ssd_hip.h -- C ABI of libssd_hip.so: the MI355X (gfx950) replacement for the SSD
+ * forward + decode/NMS hot path of FurkanOM/tf-ssd.
+ *
+ * The reference has no FFI boundary (it is Python on TensorFlow); the de-facto operator
+ * API is its Python surface.  Each entry point below names the reference
+ * interface it replaces (file:line relative to the reference root).  The Python host in
+ * tf-ssd_amd/ binds these with ctypes (tf-ssd_amd/ssd_hip.py) and keeps the reference's
+ * function names and signatures.
+ *
+ * Conventions
+ *   - extern "C", plain pointers and sizes; no torch / C++ types.
+ *   - Every `const float* / float* / int*` named *_dev or documented "device" is a device
+ *     pointer owned by the caller (e.g. torch.Tensor.data_ptr()).  The library never
+ *     frees caller memory.  Scratch comes from a caller-provided workspace whose size is
+ *     reported by the matching *_workspace_bytes() query.
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream).  All compute
+ *     entry points are asynchronous on that stream.
+ *   - Return value: 0 = ok, negative = error (SSD_E_*); text via ssd_last_error()
+ *     (thread-local).  Nothing aborts or throws across the ABI.
+ *   - Layouts: activations NHWC fp32; boxes [y1,x1,y2,x2] fp32; Keras weight layouts
+ *     (Conv2D HWIO, DepthwiseConv2D [kh,kw,C,1]) at the set_param boundary.
+ */
+#ifndef SSD_HIP_H
+#define SSD_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SSD_OK 0
+#define SSD_E_INVALID (-1)     /* bad argument (Python shim raises ValueError)          */
+#define SSD_E_HIP (-2)         /* a HIP runtime call failed                              */
+#define SSD_E_UNSUPPORTED (-3) /* valid in the reference but outside this build's limits */
+#define SSD_E_STATE (-4)       /* object used in the wrong state (e.g. not finalized)    */
+
+/* ---- library ------------------------------------------------------------------- */
+const char* ssd_version(void);
+const char* ssd_last_error(void);
+/* Select + probe the device (must be gfx950).  Replaces utils/io_utils.py:54-61
+ * (handle_gpu_compatibility) as the one-off per-process device hook. */
+int ssd_init(int device);
+
+/* ---- prior boxes: utils/bbox_utils.py:115-176 (A1-A3) ------------------------------
+ * fmaps[levels], n_ars[levels] and ars[levels][n_ars[l]] are HOST arrays; out_dev is
+ * [N,4] with N = sum f^2 * (n_ars+1).  Bit-exact vs the NumPy restatement. */
+int ssd_priors_count(const int* fmaps, const int* n_ars, int levels);
+int ssd_priors(const int* fmaps, const float* const* ars, const int* n_ars, int levels,
+               float* out_dev, void* stream);
+
+/* ---- box decode: utils/bbox_utils.py:61-85 (D1) -------------------------------------
+ * deltas [B,N,4] (device), priors [N,4] (device) -> out [B,N,4].  var (HOST, 4 floats)
+ * may be NULL; when given, deltas are multiplied by it first (models/decoder.py:41). */
+int ssd_decode_boxes(const float* priors_dev, const float* deltas_dev, const float* var,
+                     int B, int N, float* out_dev, void* stream);
+
+/* ---- SSDDecoder.call: models/decoder.py:36-55 + utils/bbox_utils.py:3-25 (D2,D3) ----
+ * and the [3P] tf.image.combined_non_max_suppression semantics.
+ * deltas [B,N,4], probs [B,N,L], priors [N,4] device; var HOST[4].
+ * Outputs (device, fully overwritten incl. zero padding rows): boxes [B,T,4] clipped to
+ * [0,1], labels [B,T] (float class id), scores [B,T], valid [B] (int32).  kept_idx_dev
+ * (nullable) [B,T] int32 receives the anchor index behind each row (-1 on padding).
+ * Tie rule (TF leaves it unspecified): equal scores -> lower anchor index, then lower
+ * class index. */
+size_t ssd_decode_nms_workspace_bytes(int B, int N, int L, int max_per_class);
+int ssd_decode_nms(const float* deltas_dev, const float* probs_dev, const float* priors_dev,
+                   const float* var, int B, int N, int L, int max_per_class, int max_total,
+                   float iou_thr, float score_thr,
+                   float* boxes_dev, float* labels_dev, float* scores_dev, int* valid_dev,
+                   int* kept_idx_dev, void* workspace_dev, size_t workspace_bytes, void* stream);
+
+/* ---- bbox_utils.non_max_suppression: utils/bbox_utils.py:3-25 (D2) -------------------
+ * Generic combined NMS on already-decoded boxes [B,N,1,4] (q == 1) and scores [B,N,C];
+ * output order as TF returns it: boxes, scores, classes, valid.  clip_boxes as TF. */
+int ssd_combined_nms(const float* boxes_dev, const float* scores_dev, int B, int N, int C,
+                     int max_per_class, int max_total, float iou_thr, float score_thr,
+                     int clip_boxes, float* boxes_out_dev, float* scores_out_dev,
+                     float* classes_out_dev, int* valid_dev, int* kept_idx_dev,
+                     void* workspace_dev, size_t workspace_bytes, void* stream);
+
+/* ---- pairwise IoU: utils/bbox_utils.py:27-59 (M1) -----------------------------------
+ * boxes [N,4] (boxes_batched == 0, shared across the batch) or [B,N,4]; gt [B,G,4];
+ * out [B,N,G].  No epsilon: 0/0 -> NaN exactly like the reference. */
+int ssd_iou_map(const float* boxes_dev, int boxes_batched, const float* gt_dev,
+                int B, int N, int G, float* out_dev, void* stream);
+
+/* ---- box encode: utils/bbox_utils.py:87-113 (M3): bboxes [N,4], gt [B,N,4] -> [B,N,4] */
+int ssd_encode_deltas(const float* bboxes_dev, const float* gt_dev, int B, int N,
+                      float* out_dev, void* stream);
+
+/* ---- target assignment: utils/train_utils.py:90-127 (M2) ----------------------------
+ * priors [N,4], gt_boxes [B,G,4], gt_labels [B,G] int32 (device); var HOST[4].
+ * deltas_out [B,N,4]; label_idx_out [B,N] int32; match_idx_out [B,N] int32 (argmax over
+ * G, first max wins) -- both bit-exact; onehot_out (nullable) [B,N,L] fp32. */
+int ssd_match_encode(const float* priors_dev, const float* gt_boxes_dev,
+                     const int* gt_labels_dev, const float* var, float iou_thr,
+                     int B, int N, int G, int L, float* deltas_out_dev,
+                     int* label_idx_out_dev, int* match_idx_out_dev, float* onehot_out_dev,
+                     void* stream);
+
+/* =====================================================================================
+ * Conv family (the TF/Keras ops the models dispatch: SURVEY.md 2.3 K1-K7).
+ * All tensors NHWC fp32 on the device.
+ * ================================================================================== */
+
+enum ssd_act { SSD_ACT_NONE = 0, SSD_ACT_RELU = 1, SSD_ACT_RELU6 = 2 };
+
+/* Geometry of one convolution.  pad_* are explicit (TF SAME / ZeroPadding2D asymmetry is
+ * resolved by the caller; ssd_same_pads() below restates the TF rule). */
+typedef struct ssd_conv_desc {
+    int B, H, W, Cin;          /* input  [B,H,W,Cin]                       */
+    int Cout, kh, kw;          /* kernel [kh,kw,Cin,Cout] (Keras HWIO)     */
+    int stride, dilation;
+    int pad_t, pad_l, pad_b, pad_r;
+    int act;                   /* enum ssd_act, applied after scale/shift  */
+    int has_residual;          /* add residual [B,Ho,Wo,Cout] before store */
+} ssd_conv_desc;
+
+/* TF SAME rule: out=ceil(in/s), p=max((out-1)*s+(k-1)*d+1-in,0),
+ * before=p/2, after=p-before.  Returns out size. */
+int ssd_same_pads(int in, int k, int stride, int dilation, int* before, int* after);
+int ssd_conv_out_size(int in, int k, int stride, int dilation, int pad_before, int pad_after);
+
+/* Packed dense-conv weights: [Npad][Kpad] fp32, K = (ky*kw+kx)*Cin+ci, zero padded
+ * (device).  scale/shift [Cout] are the folded BatchNorm (or 1/bias) epilogue vectors. */
+size_t ssd_conv_packed_weight_floats(int kh, int kw, int Cin, int Cout);
+int ssd_conv_pack_weights(const float* hwio_dev, int kh, int kw, int Cin, int Cout,
+                          float* packed_dev, void* stream);
+
+/* Conv2D (+BatchNorm +activation +residual): the MFMA implicit-GEMM kernel (K1,K3).
+ * Replaces keras Conv2D / BatchNormalization / ReLU call sites
+ * (models/ssd_mobilenet_v2.py:16-32, models/ssd_vgg16.py:52-91, models/header.py:60-61).
+ * out address of pixel (b, p=oy*Wo+ox), channel n:
+ *     out_dev + b*out_batch_stride + p*out_pixel_stride + n
+ * (pass 0 for the strides to get the dense [B,Ho,Wo,Cout] default), which is how the
+ * head convs write straight into the concatenated [B,N,K] buffers (models/header.py:34-41). */
+int ssd_conv2d(const ssd_conv_desc* d, const float* in_dev, const float* packed_w_dev,
+               const float* scale_dev, const float* shift_dev, const float* residual_dev,
+               float* out_dev, long out_batch_stride, long out_pixel_stride, void* stream);
+
+/* DepthwiseConv2D 3x3 (+BN +act): weights [3,3,C] (Keras [3,3,C,1]) device (K2). */
+int ssd_dwconv3x3(const float* in_dev, int B, int H, int W, int C, int stride,
+                  int pad_t, int pad_l, int pad_b, int pad_r,
+                  const float* w_dev, const float* scale_dev, const float* shift_dev,
+                  int act, float* out_dev, void* stream);
+
+/* MaxPool2D with TF SAME semantics (padded cells ignored): models/ssd_vgg16.py:54-73 (K4) */
+int ssd_maxpool2d(const float* in_dev, int B, int H, int W, int C, int k, int stride,
+                  int pad_t, int pad_l, int pad_b, int pad_r, float* out_dev, void* stream);
+
+/* L2Normalization: models/ssd_vgg16.py:7-31 (K5): x * rsqrt(max(sum_c x^2, 1e-12)) * gamma_c */
+int ssd_l2norm(const float* in_dev, long pixels, int C, const float* gamma_dev,
+               float* out_dev, void* stream);
+
+/* softmax over the last dim (models/header.py:64) (K7); in-place allowed. */
+int ssd_softmax(const float* in_dev, long rows, int L, float* out_dev, void* stream);
+
+/* =====================================================================================
+ * Graph runner: models/ssd_mobilenet_v2.py:7-35 (F3) / models/ssd_vgg16.py:33-97 (F6)
+ * + models/header.py:43-67 (F1,F2) [+ models/decoder.py:57-69 (D4)].
+ * A net owns its packed weights, activation arena and (optionally) a captured hipGraph.
+ * ================================================================================== */
+typedef struct ssd_net ssd_net;
+
+enum ssd_backbone { SSD_MOBILENET_V2 = 0, SSD_VGG16 = 1 };
+
+/* n_ars[levels] = len(aspect_ratios[l]) (anchors per cell = n_ars+1), total_labels = L. */
+ssd_net* ssd_net_create(int backbone, int img_size, int levels, const int* n_ars,
+                        int total_labels);
+void ssd_net_destroy(ssd_net* net);
+
+/* Parameter table in Keras order / names (e.g. "Conv1/kernel", "bn_Conv1/gamma",
+ * "block_1_expand/kernel", "extra1_1/bias", "1_conv_label_output/kernel" ...). */
+int ssd_net_num_params(const ssd_net* net);
+const char* ssd_net_param_name(const ssd_net* net, int i);
+int ssd_net_param_rank(const ssd_net* net, int i);
+const int* ssd_net_param_shape(const ssd_net* net, int i);
+/* Copy one parameter from HOST memory in its Keras layout (count = product of shape). */
+int ssd_net_set_param(ssd_net* net, const char* name, const float* host_data, size_t count);
+/* Read a parameter back (HOST), Keras layout. */
+int ssd_net_get_param(const ssd_net* net, const char* name, float* host_out, size_t count);
+/* Fold BN, pack weights for the MFMA kernels, size the arena for `max_batch`. */
+int ssd_net_finalize(ssd_net* net, int max_batch);
+int ssd_net_num_priors(const ssd_net* net);
+int ssd_net_feature_map_size(const ssd_net* net, int level);
+
+/* image [B,S,S,3] fp32 in [0,1] (device) -> pred_deltas [B,N,4], pred_labels [B,N,L]
+ * (softmax probabilities), exactly the pair the reference model outputs. */
+int ssd_net_forward(ssd_net* net, const float* image_dev, int B, float* deltas_out_dev,
+                    float* probs_out_dev, void* stream);
+
+/* Forward + SSDDecoder (get_decoder_model(...).predict on one batch): priors [N,4] dev. */
+int ssd_net_predict(ssd_net* net, const float* image_dev, int B, const float* priors_dev,
+                    const float* var, int max_total, float iou_thr, float score_thr,
+                    float* boxes_dev, float* labels_dev, float* scores_dev, int* valid_dev,
+                    void* stream);
+
+/* Debug/test hook: copy the activation of a named layer of the LAST forward to the host.
+ * Returns the element count (or negative error); host_out may be NULL to query size. */
+long ssd_net_fetch_activation(ssd_net* net, const char* layer, float* host_out, size_t cap);
+
+/* Per-layer algorithmic work of one forward at batch B (for roofline accounting). */
+int ssd_net_num_layers(const ssd_net* net);
+const char* ssd_net_layer_name(const ssd_net* net, int i);
+const char* ssd_net_layer_kind(const ssd_net* net, int i);   /* "conv","dw","pool",... */
+double ssd_net_layer_flops(const ssd_net* net, int i, int B); /* 2*MACs                  */
+double ssd_net_layer_bytes(const ssd_net* net, int i, int B); /* in + out + weights      */
+/* Time every layer with hipEvents on `stream` (reps forwards); ms_out[num_layers]. */
+int ssd_net_profile_layers(ssd_net* net, const float* image_dev, int B, int reps,
+                           float* ms_out, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SSD_HIP_H */

@@ -1,0 +1,192 @@
+"""GPU parity tests for the box family: HIP kernels (through the C ABI / ctypes surface)
+vs the CPU oracle on the same seeded inputs and vs the committed golden fixtures.
+Bar: bit-exact indices (kept anchors, match indices, labels, valid counts); priors
+bit-exact; boxes/scores/deltas within 1e-4 abs (tolerance of BASELINE.json north_star;
+observed ~1e-7, the only non-exact ops being expf/logf last-ulp)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import helpers
+from oracle import bbox_oracle as bo
+from oracle import c_oracle as co
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+TOL = 1e-4
+
+
+def _np(t):
+    return t.detach().cpu().numpy()
+
+
+@pytest.fixture(scope="module")
+def bbox_utils():
+    from utils import bbox_utils as m
+    return m
+
+
+@pytest.mark.parametrize("backbone", ["mobilenet_v2", "vgg16"])
+def test_priors_bit_exact(bbox_utils, backbone):
+    p = _np(bbox_utils.generate_prior_boxes(helpers.FMAPS[backbone], helpers.ASPECT_RATIOS))
+    gold = np.load(os.path.join(GOLD, "priors.npz"))[backbone]
+    np.testing.assert_array_equal(p, gold)
+
+
+def test_priors_other_configs(bbox_utils):
+    for fm in ([32, 16, 8, 4, 2, 1], [64, 32, 16, 8, 6, 4], [3, 1]):
+        ars = helpers.ASPECT_RATIOS[:len(fm)]
+        np.testing.assert_array_equal(_np(bbox_utils.generate_prior_boxes(fm, ars)),
+                                      bo.generate_prior_boxes(fm, ars))
+    with pytest.raises(ZeroDivisionError):      # same failure as the reference's A1 with m == 1
+        bbox_utils.generate_prior_boxes([7], helpers.ASPECT_RATIOS[:1])
+    b = bbox_utils.generate_base_prior_boxes([1., 2., 0.5], 1, 6)
+    np.testing.assert_array_equal(_np(b), bo.generate_base_prior_boxes([1., 2., 0.5], 1, 6))
+
+
+def test_decode_boxes(bbox_utils):
+    p = np.load(os.path.join(GOLD, "priors.npz"))["vgg16"]
+    d, _ = helpers.decoder_inputs(3, p.shape[0], seed=4)
+    out = _np(bbox_utils.get_bboxes_from_deltas(p, d))
+    ref = co.decode(p, d, [1, 1, 1, 1])
+    # exp() of N(0,1) deltas: relative tolerance on the (unclipped) boxes
+    np.testing.assert_allclose(out, ref, rtol=2e-6, atol=1e-6)
+
+
+@pytest.mark.parametrize("name", ["rand", "none", "ties", "degenerate"])
+def test_decoder_golden(name):
+    from models.decoder import SSDDecoder
+    z = np.load(os.path.join(GOLD, "decode_nms.npz"))
+    p = np.load(os.path.join(GOLD, "priors.npz"))["mobilenet_v2"]
+    dec = SSDDecoder(p, helpers.VARIANCES)
+    b, l, s = dec.call([z[name + "_deltas"], z[name + "_probs"]], return_indices=True)
+    np.testing.assert_array_equal(_np(dec.last_kept_indices), z[name + "_idx"])
+    np.testing.assert_array_equal(_np(dec.last_valid_detections), z[name + "_valid"])
+    np.testing.assert_array_equal(_np(l), z[name + "_labels"])
+    np.testing.assert_array_equal(_np(s), z[name + "_scores"])
+    np.testing.assert_allclose(_np(b), z[name + "_boxes"], atol=TOL, rtol=0)
+    assert np.abs(_np(b) - z[name + "_boxes"]).max() < 1e-6
+
+
+@pytest.mark.parametrize("B,N,L,seed,frac", [(4, 2268, 21, 31, 0.10), (2, 8732, 21, 32, 0.10),
+                                             (2, 24564, 21, 33, 0.10), (3, 2268, 21, 34, 0.9),
+                                             (1, 100, 3, 35, 0.5), (2, 1, 21, 36, 1.0), (5, 333, 91, 37, 0.2)])
+def test_decoder_vs_c_oracle(B, N, L, seed, frac):
+    """Sizes up to the 24 564-anchor stress (BASELINE config 5) against the plain-C oracle."""
+    from models.decoder import SSDDecoder
+    rng = np.random.default_rng(seed)
+    c = rng.uniform(0.05, 0.95, (N, 2)); sz = rng.uniform(0.02, 0.4, (N, 2))
+    p = np.clip(np.concatenate([c - sz / 2, c + sz / 2], -1), 0, 1).astype(np.float32)
+    d, pr = helpers.decoder_inputs(B, N, L, seed=seed, boost_frac=frac)
+    dec = SSDDecoder(p, helpers.VARIANCES)
+    b, l, s = dec.call([d, pr], return_indices=True)
+    rb, rl, rs, rv, ri = co.decode_nms(d, pr, p, helpers.VARIANCES)
+    np.testing.assert_array_equal(_np(dec.last_valid_detections), rv)
+    np.testing.assert_array_equal(_np(dec.last_kept_indices), ri)
+    np.testing.assert_array_equal(_np(l), rl)
+    np.testing.assert_array_equal(_np(s), rs)
+    np.testing.assert_allclose(_np(b), rb, atol=TOL, rtol=0)
+
+
+def test_decoder_many_candidates_per_class():
+    """> 4096 candidates in one class exercises the in-HBM sort fallback; > 256 exercises
+    multi-chunk suppression; max_total smaller than the survivors exercises truncation."""
+    from models.decoder import SSDDecoder
+    N, L = 9000, 4
+    rng = np.random.default_rng(41)
+    c = rng.uniform(0.0, 1.0, (N, 2)); sz = rng.uniform(0.01, 0.05, (N, 2))
+    p = np.clip(np.concatenate([c - sz / 2, c + sz / 2], -1), 0, 1).astype(np.float32)
+    d = (rng.standard_normal((1, N, 4)) * 0.1).astype(np.float32)
+    pr = np.zeros((1, N, L), np.float32)
+    pr[0, :, 2] = rng.uniform(0.5001, 0.999, N).astype(np.float32)
+    pr[0, :, 0] = 1 - pr[0, :, 2]
+    pr[0, ::2, 1] = 0.0
+    for T in (200, 50, 1000):
+        dec = SSDDecoder(p, helpers.VARIANCES, max_total_size=T)
+        b, l, s = dec.call([d, pr], return_indices=True)
+        rb, rl, rs, rv, ri = co.decode_nms(d, pr, p, helpers.VARIANCES, max_per_class=T, max_total=T)
+        np.testing.assert_array_equal(_np(dec.last_kept_indices), ri)
+        np.testing.assert_array_equal(_np(dec.last_valid_detections), rv)
+        np.testing.assert_array_equal(_np(s), rs)
+        np.testing.assert_allclose(_np(b), rb, atol=TOL, rtol=0)
+
+
+def test_decoder_empty_and_errors():
+    from models.decoder import SSDDecoder
+    p = np.load(os.path.join(GOLD, "priors.npz"))["mobilenet_v2"]
+    dec = SSDDecoder(p, helpers.VARIANCES)
+    b, l, s = dec([np.zeros((0, 2268, 4), np.float32), np.zeros((0, 2268, 21), np.float32)])
+    assert b.shape == (0, 200, 4) and l.shape == (0, 200) and s.shape == (0, 200)
+    with pytest.raises(ValueError):
+        dec([np.zeros((1, 10, 4), np.float32), np.zeros((1, 10, 21), np.float32)])
+    cfg = dec.get_config()
+    assert cfg["max_total_size"] == 200 and cfg["score_threshold"] == 0.5 and cfg["prior_boxes"].shape == (2268, 4)
+
+
+def test_combined_nms_raw(bbox_utils):
+    """bbox_utils.non_max_suppression on raw boxes incl. inverted / zero-area boxes, negative
+    threshold and column 0 as an ordinary class."""
+    rng = np.random.default_rng(51)
+    B, N, C = 3, 500, 5
+    c = rng.uniform(0.0, 1.0, (B, N, 2)); sz = rng.uniform(-0.1, 0.4, (B, N, 2))
+    boxes = np.concatenate([c - sz / 2, c + sz / 2], -1).astype(np.float32)   # some inverted
+    boxes[:, ::17, 2:] = boxes[:, ::17, :2]                                     # zero area
+    scores = rng.uniform(0, 1, (B, N, C)).astype(np.float32)
+    for thr, mpc, mt in ((0.5, 200, 200), (-1.0, 30, 40), (0.9, 5, 200)):
+        ob, osc, oc, v = bbox_utils.non_max_suppression(boxes[:, :, None, :], scores,
+                                                        max_output_size_per_class=mpc, max_total_size=mt,
+                                                        score_threshold=thr)
+        rb, rs, rc, rv = bo.combined_non_max_suppression(boxes, scores, mpc, mt, 0.5, thr)
+        np.testing.assert_array_equal(_np(v), rv)
+        np.testing.assert_array_equal(_np(oc), rc)
+        np.testing.assert_array_equal(_np(osc), rs)
+        np.testing.assert_array_equal(_np(ob), rb)
+    with pytest.raises(TypeError):
+        bbox_utils.non_max_suppression(boxes[:, :, None, :], scores)
+
+
+def test_iou_map_and_match(bbox_utils):
+    from utils import train_utils
+    z = np.load(os.path.join(GOLD, "match.npz"))
+    p = np.load(os.path.join(GOLD, "priors.npz"))["mobilenet_v2"]
+    np.testing.assert_array_equal(_np(bbox_utils.generate_iou_map(p, z["gt"])), z["iou"])
+    hp = helpers.hyper_params()
+    d, oh, lab, mi = train_utils.calculate_actual_outputs(p, z["gt"], z["gl"], hp, return_indices=True)
+    np.testing.assert_array_equal(_np(lab), z["label_idx"])
+    np.testing.assert_array_equal(_np(mi), z["match_idx"])
+    np.testing.assert_allclose(_np(d), z["deltas"], atol=TOL, rtol=0)
+    assert np.abs(_np(d) - z["deltas"]).max() < 1e-5
+    oh = _np(oh)
+    assert (oh.argmax(-1) == z["label_idx"]).all() and (oh.sum(-1) == 1).all()
+    # batched boxes x gt (eval_utils usage) and 2-d x 2-d
+    bb = np.broadcast_to(p[None, :200], (4, 200, 4)).copy()
+    np.testing.assert_array_equal(_np(bbox_utils.generate_iou_map(bb, z["gt"])), bo.generate_iou_map(bb, z["gt"]))
+    np.testing.assert_array_equal(_np(bbox_utils.generate_iou_map(p[:50], z["gt"][0])),
+                                  bo.generate_iou_map(p[:50], z["gt"][0]))
+    # NaN for 0/0 like the reference
+    assert torch.isnan(bbox_utils.generate_iou_map(np.zeros((1, 4), np.float32), np.zeros((1, 1, 4), np.float32))).all()
+
+
+def test_match_full_size_vs_c(bbox_utils):
+    """BASELINE config 4 shape: 32 images/GPU, VGG priors, G=16."""
+    from utils import train_utils
+    p = np.load(os.path.join(GOLD, "priors.npz"))["vgg16"]
+    gt, gl = helpers.gt_inputs(32, seed=61)
+    hp = helpers.hyper_params("vgg16")
+    d, oh, lab, mi = train_utils.calculate_actual_outputs(p, gt, gl, hp, return_indices=True)
+    rd, rl, rm = co.match_encode(p, gt, gl, helpers.VARIANCES)
+    np.testing.assert_array_equal(_np(lab), rl)
+    np.testing.assert_array_equal(_np(mi), rm)
+    np.testing.assert_allclose(_np(d), rd, atol=TOL, rtol=0)
+
+
+def test_encode_decode_roundtrip_gpu(bbox_utils):
+    p = np.load(os.path.join(GOLD, "priors.npz"))["mobilenet_v2"]
+    d, _ = helpers.decoder_inputs(2, p.shape[0], seed=71)
+    d *= 0.3
+    boxes = bbox_utils.get_bboxes_from_deltas(p, d)
+    back = _np(bbox_utils.get_deltas_from_bboxes(p, boxes))
+    np.testing.assert_allclose(back, d, atol=2e-4)
+    np.testing.assert_allclose(back, bo.get_deltas_from_bboxes(p, _np(boxes)), atol=1e-5)

@@ -1,0 +1,30 @@
+#!/bin/bash
+# Builds libssd_hip.so (gfx950 only) in-tree.  Usage: build.sh [-f]
+set -e
+cd "$(dirname "$0")"
+OUT=../libssd_hip.so
+HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
+COMMON="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function"
+mkdir -p build
+need_link=0
+compile() {  # src extra-flags
+  local src=$1; shift
+  local obj=build/${src%.*}.o
+  if [ "$FORCE" = 1 ] || [ ! -f "$obj" ] || [ "$src" -nt "$obj" ] || [ common.h -nt "$obj" ] \
+     || [ ../../include/ssd_hip.h -nt "$obj" ] || { [ -f "${src%.*}.h" ] && [ "${src%.*}.h" -nt "$obj" ]; }; then
+    echo "hipcc $src"
+    $HIPCC $COMMON "$@" -c "$src" -o "$obj"
+    need_link=1
+  fi
+}
+[ "$1" = "-f" ] && FORCE=1
+# box math: separately-rounded fp32 ops (bit-exact indices vs the oracle)
+compile ssd_core.hip
+compile ssd_bbox.hip -ffp-contract=off -fhip-fp32-correctly-rounded-divide-sqrt
+for s in ssd_conv.hip ssd_ops.hip ssd_net.hip ssd_stubs_tmp.hip; do
+  [ -f "$s" ] && compile "$s"
+done
+if [ $need_link = 1 ] || [ ! -f $OUT ]; then
+  echo "link $OUT"
+  $HIPCC --offload-arch=gfx950 -shared -fPIC -o $OUT build/*.o
+fi

@@ -1,0 +1,158 @@
+"""ctypes binding of libssd_hip.so (include/ssd_hip.h) -- the only door from the Python
+host code to the HIP kernels.  PyTorch-ROCm is used for device memory and streams only.
+
+There is deliberately NO CPU fallback: if the shared library is missing, or no gfx950
+device is visible, every compute entry point raises.
+"""
+import ctypes
+import os
+
+import numpy as np
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libssd_hip.so")
+
+c_float_p = ctypes.POINTER(ctypes.c_float)
+c_int_p = ctypes.POINTER(ctypes.c_int)
+vp = ctypes.c_void_p
+
+
+class ConvDesc(ctypes.Structure):
+    """struct ssd_conv_desc (include/ssd_hip.h)."""
+    _fields_ = [(n, ctypes.c_int) for n in (
+        "B", "H", "W", "Cin", "Cout", "kh", "kw", "stride", "dilation",
+        "pad_t", "pad_l", "pad_b", "pad_r", "act", "has_residual")]
+
+
+ACT_NONE, ACT_RELU, ACT_RELU6 = 0, 1, 2
+MOBILENET_V2, VGG16 = 0, 1
+
+# name -> (restype, argtypes); every symbol include/ssd_hip.h declares.
+_SIGNATURES = {
+    "ssd_version": (ctypes.c_char_p, []),
+    "ssd_last_error": (ctypes.c_char_p, []),
+    "ssd_init": (ctypes.c_int, [ctypes.c_int]),
+    "ssd_priors_count": (ctypes.c_int, [c_int_p, c_int_p, ctypes.c_int]),
+    "ssd_priors": (ctypes.c_int, [c_int_p, ctypes.POINTER(c_float_p), c_int_p, ctypes.c_int, vp, vp]),
+    "ssd_decode_boxes": (ctypes.c_int, [vp, vp, c_float_p, ctypes.c_int, ctypes.c_int, vp, vp]),
+    "ssd_decode_nms_workspace_bytes": (ctypes.c_size_t, [ctypes.c_int] * 4),
+    "ssd_decode_nms": (ctypes.c_int, [vp, vp, vp, c_float_p] + [ctypes.c_int] * 5 +
+                       [ctypes.c_float, ctypes.c_float, vp, vp, vp, vp, vp, vp, ctypes.c_size_t, vp]),
+    "ssd_combined_nms": (ctypes.c_int, [vp, vp] + [ctypes.c_int] * 5 +
+                         [ctypes.c_float, ctypes.c_float, ctypes.c_int, vp, vp, vp, vp, vp, vp,
+                          ctypes.c_size_t, vp]),
+    "ssd_iou_map": (ctypes.c_int, [vp, ctypes.c_int, vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, vp, vp]),
+    "ssd_encode_deltas": (ctypes.c_int, [vp, vp, ctypes.c_int, ctypes.c_int, vp, vp]),
+    "ssd_match_encode": (ctypes.c_int, [vp, vp, vp, c_float_p, ctypes.c_float] + [ctypes.c_int] * 4 +
+                         [vp, vp, vp, vp, vp]),
+    "ssd_same_pads": (ctypes.c_int, [ctypes.c_int] * 4 + [c_int_p, c_int_p]),
+    "ssd_conv_out_size": (ctypes.c_int, [ctypes.c_int] * 6),
+    "ssd_conv_packed_weight_floats": (ctypes.c_size_t, [ctypes.c_int] * 4),
+    "ssd_conv_pack_weights": (ctypes.c_int, [vp] + [ctypes.c_int] * 4 + [vp, vp]),
+    "ssd_conv2d": (ctypes.c_int, [ctypes.POINTER(ConvDesc), vp, vp, vp, vp, vp, vp,
+                                  ctypes.c_long, ctypes.c_long, vp]),
+    "ssd_dwconv3x3": (ctypes.c_int, [vp] + [ctypes.c_int] * 9 + [vp, vp, vp, ctypes.c_int, vp, vp]),
+    "ssd_maxpool2d": (ctypes.c_int, [vp] + [ctypes.c_int] * 10 + [vp, vp]),
+    "ssd_l2norm": (ctypes.c_int, [vp, ctypes.c_long, ctypes.c_int, vp, vp, vp]),
+    "ssd_softmax": (ctypes.c_int, [vp, ctypes.c_long, ctypes.c_int, vp, vp]),
+    "ssd_net_create": (vp, [ctypes.c_int, ctypes.c_int, ctypes.c_int, c_int_p, ctypes.c_int]),
+    "ssd_net_destroy": (None, [vp]),
+    "ssd_net_num_params": (ctypes.c_int, [vp]),
+    "ssd_net_param_name": (ctypes.c_char_p, [vp, ctypes.c_int]),
+    "ssd_net_param_rank": (ctypes.c_int, [vp, ctypes.c_int]),
+    "ssd_net_param_shape": (c_int_p, [vp, ctypes.c_int]),
+    "ssd_net_set_param": (ctypes.c_int, [vp, ctypes.c_char_p, c_float_p, ctypes.c_size_t]),
+    "ssd_net_get_param": (ctypes.c_int, [vp, ctypes.c_char_p, c_float_p, ctypes.c_size_t]),
+    "ssd_net_finalize": (ctypes.c_int, [vp, ctypes.c_int]),
+    "ssd_net_num_priors": (ctypes.c_int, [vp]),
+    "ssd_net_feature_map_size": (ctypes.c_int, [vp, ctypes.c_int]),
+    "ssd_net_forward": (ctypes.c_int, [vp, vp, ctypes.c_int, vp, vp, vp]),
+    "ssd_net_predict": (ctypes.c_int, [vp, vp, ctypes.c_int, vp, c_float_p, ctypes.c_int,
+                                       ctypes.c_float, ctypes.c_float, vp, vp, vp, vp, vp]),
+    "ssd_net_fetch_activation": (ctypes.c_long, [vp, ctypes.c_char_p, c_float_p, ctypes.c_size_t]),
+    "ssd_net_num_layers": (ctypes.c_int, [vp]),
+    "ssd_net_layer_name": (ctypes.c_char_p, [vp, ctypes.c_int]),
+    "ssd_net_layer_kind": (ctypes.c_char_p, [vp, ctypes.c_int]),
+    "ssd_net_layer_flops": (ctypes.c_double, [vp, ctypes.c_int, ctypes.c_int]),
+    "ssd_net_layer_bytes": (ctypes.c_double, [vp, ctypes.c_int, ctypes.c_int]),
+    "ssd_net_profile_layers": (ctypes.c_int, [vp, vp, ctypes.c_int, ctypes.c_int, c_float_p, vp]),
+}
+
+_lib = None
+_inited = False
+_workspaces = {}
+
+
+class SsdHipError(RuntimeError):
+    pass
+
+
+def lib():
+    """Load libssd_hip.so (no GPU needed for loading).  Raises if it was not built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise SsdHipError(
+                "libssd_hip.so is missing (%s). Build it with tf-ssd_amd/csrc/build.sh or "
+                "__graft_entry__.build(); there is no CPU fallback." % LIB_PATH)
+        l = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in _SIGNATURES.items():
+            fn = getattr(l, name)    # AttributeError here == the .so is stale: rebuild it
+            fn.restype = res
+            fn.argtypes = args
+        _lib = l
+    return _lib
+
+
+def check(rc, what=""):
+    if rc != 0:
+        msg = lib().ssd_last_error().decode()
+        if rc == -1:
+            raise ValueError("%s: %s" % (what, msg))
+        raise SsdHipError("%s failed (%d): %s" % (what, rc, msg))
+
+
+def device():
+    """The torch device of this process (one process per GPU: LOCAL_RANK selects it)."""
+    global _inited
+    if not torch.cuda.is_available():
+        raise SsdHipError("no HIP device visible: the SSD kernels need an MI355X (gfx950); "
+                          "there is no CPU fallback")
+    idx = torch.cuda.current_device()
+    if not _inited:
+        check(lib().ssd_init(idx), "ssd_init")
+        _inited = True
+    return torch.device("cuda", idx)
+
+
+def stream():
+    return vp(torch.cuda.current_stream().cuda_stream)
+
+
+def to_dev(x, dtype=torch.float32):
+    """numpy / list / torch (any device) -> contiguous tensor on the GPU."""
+    dev = device()
+    if isinstance(x, torch.Tensor):
+        return x.to(device=dev, dtype=dtype).contiguous()
+    return torch.as_tensor(np.ascontiguousarray(np.asarray(x)), dtype=dtype).to(dev).contiguous()
+
+
+def ptr(t):
+    return vp(t.data_ptr()) if t is not None else vp(0)
+
+
+def host4(v):
+    a = (ctypes.c_float * 4)(*[float(x) for x in v])
+    return ctypes.cast(a, c_float_p), a
+
+
+def workspace(nbytes):
+    """Grow-only scratch buffer per device (caller-owned memory, as the ABI requires)."""
+    dev = device()
+    key = dev.index
+    ws = _workspaces.get(key)
+    if ws is None or ws.numel() < nbytes:
+        ws = torch.empty(int(nbytes), dtype=torch.uint8, device=dev)
+        _workspaces[key] = ws
+    return ws
