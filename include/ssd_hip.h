@@ -141,6 +141,15 @@ int ssd_conv2d(const ssd_conv_desc* d, const float* in_dev, const float* packed_
                const float* scale_dev, const float* shift_dev, const float* residual_dev,
                float* out_dev, long out_batch_stride, long out_pixel_stride, void* stream);
 
+/* Tuning / test hooks of the same kernel family: explicit tile configuration (-1 = cost
+ * model), optional deterministic split-K (split_k > 1 needs split_k*M*Cout floats). */
+int ssd_conv_num_configs(void);
+const char* ssd_conv_config_name(int config);
+int ssd_conv2d_ex(const ssd_conv_desc* d, const float* in_dev, const float* packed_w_dev,
+                  const float* scale_dev, const float* shift_dev, const float* residual_dev,
+                  float* out_dev, long out_batch_stride, long out_pixel_stride, int config,
+                  int split_k, float* splitk_ws_dev, void* stream);
+
 /* DepthwiseConv2D 3x3 (+BN +act): weights [3,3,C] (Keras [3,3,C,1]) device (K2). */
 int ssd_dwconv3x3(const float* in_dev, int B, int H, int W, int C, int stride,
                   int pad_t, int pad_l, int pad_b, int pad_r,
@@ -206,6 +215,7 @@ long ssd_net_fetch_activation(ssd_net* net, const char* layer, float* host_out, 
 int ssd_net_num_layers(const ssd_net* net);
 const char* ssd_net_layer_name(const ssd_net* net, int i);
 const char* ssd_net_layer_kind(const ssd_net* net, int i);   /* "conv","dw","pool",... */
+const char* ssd_net_layer_config(const ssd_net* net, int i); /* autotuned conv tile config */
 double ssd_net_layer_flops(const ssd_net* net, int i, int B); /* 2*MACs                  */
 double ssd_net_layer_bytes(const ssd_net* net, int i, int B); /* in + out + weights      */
 /* Time every layer with hipEvents on `stream` (reps forwards); ms_out[num_layers]. */

@@ -45,3 +45,65 @@ def gt_inputs(B, G=16, L=21, seed=3):
 
 def images(B, S=300, seed=0):
     return np.random.default_rng(seed).random((B, S, S, 3), dtype=np.float32)
+
+
+_WCACHE = {}
+
+
+def synthetic_weights(backbone, hp=None, seed=1, target_frac=0.05):
+    """Seeded synthetic weights: He-normal conv kernels in Keras HWIO layout,
+    BN gamma 1+-0.1, beta +-0.1, mean +-0.1, var in [0.5,1.5]; the background bias of the
+    label heads is shifted (bisection on the oracle's logits of one image) so that about
+    ``target_frac`` of the anchors have a non-background probability > 0.5 -- otherwise NMS
+    would be a no-op with random weights.  Returns dict name -> float32 array."""
+    from oracle import net_oracle as no
+    hp = hp or hyper_params(backbone)
+    key = (backbone, seed, target_frac, hp["total_labels"], hp["img_size"])
+    if key in _WCACHE:
+        return _WCACHE[key]
+    rng = np.random.default_rng(seed)
+    w = {}
+    for name, shape in no.param_specs(backbone, hp):
+        var = name.rsplit("/", 1)[1]
+        if var == "kernel":
+            fan_in = shape[0] * shape[1] * shape[2]
+            w[name] = (rng.standard_normal(shape) * np.sqrt(2.0 / fan_in)).astype(np.float32)
+        elif var == "depthwise_kernel":
+            w[name] = (rng.standard_normal(shape) * np.sqrt(2.0 / 9.0)).astype(np.float32)
+        elif var == "gamma":
+            w[name] = rng.uniform(0.9, 1.1, shape).astype(np.float32)
+        elif var in ("beta", "moving_mean"):
+            w[name] = rng.uniform(-0.1, 0.1, shape).astype(np.float32)
+        elif var == "moving_variance":
+            w[name] = rng.uniform(0.5, 1.5, shape).astype(np.float32)
+        elif var == "scale":
+            w[name] = np.full(shape, 20.0, np.float32)
+        else:  # bias
+            w[name] = rng.uniform(-0.05, 0.05, shape).astype(np.float32)
+    # tame the head logits, then calibrate the background bias
+    L = hp["total_labels"]
+    for i in range(1, 7):
+        w["%d_conv_label_output/kernel" % i] *= np.float32(0.5)
+        w["%d_conv_boxes_output/kernel" % i] *= np.float32(0.25)
+    acts = {}
+    no.forward(backbone, hp, w, images(1, hp["img_size"], seed=0), acts)
+    logits = acts["labels_head"][0].astype(np.float64)            # [N, L]
+
+    def frac(t):
+        lg = logits.copy()
+        lg[:, 0] += t
+        e = np.exp(lg - lg.max(-1, keepdims=True))
+        p = e / e.sum(-1, keepdims=True)
+        return float(((p.argmax(-1) != 0) & (p.max(-1) > 0.5)).mean())
+    lo, hi = -50.0, 50.0
+    for _ in range(40):
+        mid = 0.5 * (lo + hi)
+        if frac(mid) > target_frac:
+            lo = mid
+        else:
+            hi = mid
+    t = np.float32(0.5 * (lo + hi))
+    for i in range(1, 7):
+        w["%d_conv_label_output/bias" % i][0::L] += t
+    _WCACHE[key] = w
+    return w

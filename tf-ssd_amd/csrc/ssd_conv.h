@@ -1,0 +1,53 @@
+// Internal interface between the conv kernels (ssd_conv.hip / ssd_ops.hip) and the graph
+// runner (ssd_net.hip).
+#pragma once
+#include "common.h"
+
+namespace ssd {
+
+// Fully resolved launch parameters of one dense convolution (implicit GEMM view:
+// out[M = B*Ho*Wo, N = Cout] = X[M, K = kh*kw*Cin] * W[K, N]).
+struct ConvParams {
+    const float* in;
+    const float* w;        // packed [Npad][Kpad]
+    const float* scale;    // [Cout] or nullptr (== 1)
+    const float* shift;    // [Cout] or nullptr (== 0)
+    const float* residual; // dense [M][Cout] or nullptr
+    float* out;
+    int B, H, W, Cin, Ho, Wo, Cout;
+    int kh, kw, stride, dil, pad_t, pad_l;
+    int K, Kpad, Npad;
+    long M;
+    long out_batch_stride, out_pixel_stride;
+    int act;
+    int vec_store;         // 1: float4 stores are aligned
+    int split_k;           // >1: partial sums to `partial` [split][M][Cout], epilogue deferred
+    float* partial;
+};
+
+inline int round_up(int v, int a) { return (v + a - 1) / a * a; }
+inline int conv_kpad(int K) { return round_up(K, 32); }
+inline int conv_npad(int Cout) { return round_up(Cout, 16); }
+
+int conv_num_configs();
+const char* conv_config_name(int cfg);
+// true if config `cfg` can run these parameters (alignment / shape constraints).
+bool conv_config_valid(int cfg, const ConvParams& p);
+int conv_pick_config(const ConvParams& p);                 // heuristic
+int conv_launch(const ConvParams& p, int cfg, hipStream_t st);
+size_t conv_splitk_workspace_floats(const ConvParams& p, int cfg);
+
+int fill_conv_params(const ssd_conv_desc* d, ConvParams* p);   // geometry + validation
+
+int launch_dwconv3x3(const float* in, int B, int H, int W, int C, int stride, int pad_t, int pad_l,
+                     int Ho, int Wo, const float* w, const float* scale, const float* shift, int act,
+                     float* out, hipStream_t st);
+int launch_maxpool(const float* in, int B, int H, int W, int C, int k, int stride, int pad_t, int pad_l,
+                   int Ho, int Wo, float* out, hipStream_t st);
+int launch_l2norm(const float* in, long pixels, int C, const float* gamma, float* out, hipStream_t st);
+int launch_softmax(const float* in, long rows, int L, float* out, hipStream_t st);
+int launch_pack_weights(const float* hwio, int K, int Cout, int Kpad, int Npad, float* packed, hipStream_t st);
+int launch_fold_bn(const float* gamma, const float* beta, const float* mean, const float* var, float eps,
+                   int C, float* scale, float* shift, hipStream_t st);
+
+}  // namespace ssd

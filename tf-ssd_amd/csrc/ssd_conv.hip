@@ -1,0 +1,524 @@
+// Dense convolution for gfx950 as an implicit GEMM on the fp32 matrix cores.
+//
+//   out[m, n] = act( sum_k X[m, k] * W[k, n] * scale[n] + shift[n] ) (+ residual[m, n])
+//   m = (b, oy, ox) output pixel, n = output channel, k = (ky, kx, ci)
+//
+// Mapping to CDNA4 (MI355X):
+//   * v_mfma_f32_16x16x4_f32 (exact fp32, 256 FLOP/clk/CU): the WEIGHTS are the MFMA "A"
+//     operand and the PIXELS the "B" operand, so each lane ends up holding 4 consecutive
+//     output channels of one pixel -> one 16-byte store per accumulator tile, and the
+//     per-channel scale/shift (folded BatchNorm or bias) is a 16-byte load.
+//   * Both operands are K-contiguous (NHWC activations; weights pre-packed [N][K]), so a
+//     lane fetches 4 consecutive k with one ds_read_b128 and feeds 4 MFMA k-steps from it
+//     (the MFMA k index is a summation index: any bijection shared by A and B is valid).
+//   * 256-thread blocks = 4 waves (WM x WN), wave tile (16*MT) x (16*NT); LDS tiles
+//     [rows][BK+4] (16-byte padded rows); global->register prefetch of the next K tile is in
+//     flight while the current one is multiplied.
+//   * im2col is never materialised: for k x k convs the per-row (b, iy0, ix0) is decoded
+//     once per block and each K tile (BK | Cin) lies inside one filter tap; TF's asymmetric
+//     SAME / ZeroPadding2D pads are explicit (pad_t, pad_l) and out-of-image taps load zeros.
+//   * The epilogue writes through (batch stride, pixel stride) so the SSD head convs store
+//     straight into the concatenated [B, N, K] buffers (reference models/header.py:34-41).
+#include "ssd_conv.h"
+
+namespace ssd {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ float apply_act(float v, int act) {
+    if (act == SSD_ACT_RELU) return fmaxf(v, 0.0f);
+    if (act == SSD_ACT_RELU6) return fminf(fmaxf(v, 0.0f), 6.0f);
+    return v;
+}
+
+template <int MT, int NT, int WM, int WN, int BK, bool GEMM1X1>
+__global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvParams p) {
+    constexpr int BM = 16 * MT * WM, BN = 16 * NT * WN;
+    constexpr int LDK = BK + 4;
+    constexpr int UPR = BK / 4;                 // float4 units per tile row
+    constexpr int XU = BM * UPR, WU = BN * UPR;
+    constexpr int XP = (XU + 255) / 256, WP = (WU + 255) / 256;
+    static_assert(WM * WN == 4, "4 waves per block");
+    __shared__ __attribute__((aligned(16))) float smem[(BM + BN) * LDK];
+    float* Xs = smem;
+    float* Ws = smem + BM * LDK;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int nb_n = (p.Cout + BN - 1) / BN;
+    const int mblk = blockIdx.x / nb_n, nblk = blockIdx.x - mblk * nb_n;
+    const long m0 = (long)mblk * BM;
+    const int n0 = nblk * BN;
+    const int HoWo = p.Ho * p.Wo;
+
+    // ---- per-thread load bookkeeping (rows are the same for every K tile)
+    const float* xrow[XP];
+    int xiy0[XP], xix0[XP];
+    bool xok[XP];
+#pragma unroll
+    for (int ps = 0; ps < XP; ++ps) {
+        const int u = tid + ps * 256;
+        const int row = u / UPR;
+        const long m = m0 + row;
+        xok[ps] = (u < XU) && (m < p.M);
+        xiy0[ps] = xix0[ps] = 0;
+        if (GEMM1X1) {
+            xrow[ps] = p.in + (xok[ps] ? m : 0) * p.Cin;
+        } else {
+            const long mm = xok[ps] ? m : 0;
+            const int b = (int)(mm / HoWo);
+            const int pix = (int)(mm - (long)b * HoWo);
+            const int oy = pix / p.Wo, ox = pix - oy * p.Wo;
+            xiy0[ps] = oy * p.stride - p.pad_t;
+            xix0[ps] = ox * p.stride - p.pad_l;
+            xrow[ps] = p.in + (long)b * p.H * p.W * p.Cin;
+        }
+    }
+    const int kq4 = (tid % UPR) * 4;           // identical for every pass (256 % UPR == 0)
+
+    const int nkt_total = (p.K + BK - 1) / BK;
+    int kt_begin = 0, kt_end = nkt_total;
+    if (p.split_k > 1) {
+        const int per = (nkt_total + p.split_k - 1) / p.split_k;
+        kt_begin = blockIdx.y * per;
+        kt_end = min(nkt_total, kt_begin + per);
+    }
+
+    f32x4 xr[XP], wr[WP];
+    auto load_tile = [&](int kt) {
+        const int k0 = kt * BK;
+        if (GEMM1X1) {
+            const int k = k0 + kq4;
+#pragma unroll
+            for (int ps = 0; ps < XP; ++ps) {
+                xr[ps] = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (xok[ps] && k < p.K) xr[ps] = *reinterpret_cast<const f32x4*>(xrow[ps] + k);
+            }
+        } else {
+            const int tap = k0 / p.Cin;
+            const int ci = k0 - tap * p.Cin + kq4;
+            const int ky = tap / p.kw, kx = tap - ky * p.kw;
+#pragma unroll
+            for (int ps = 0; ps < XP; ++ps) {
+                const int iy = xiy0[ps] + ky * p.dil, ix = xix0[ps] + kx * p.dil;
+                xr[ps] = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (xok[ps] && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W)
+                    xr[ps] = *reinterpret_cast<const f32x4*>(xrow[ps] + ((long)iy * p.W + ix) * p.Cin + ci);
+            }
+        }
+#pragma unroll
+        for (int ps = 0; ps < WP; ++ps) {
+            const int u = tid + ps * 256;
+            const int n = n0 + u / UPR;
+            wr[ps] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (u < WU && n < p.Npad)
+                wr[ps] = *reinterpret_cast<const f32x4*>(p.w + (long)n * p.Kpad + k0 + kq4);
+        }
+    };
+    auto store_tile = [&]() {
+#pragma unroll
+        for (int ps = 0; ps < XP; ++ps) {
+            const int u = tid + ps * 256;
+            if (u < XU) *reinterpret_cast<f32x4*>(Xs + (u / UPR) * LDK + kq4) = xr[ps];
+        }
+#pragma unroll
+        for (int ps = 0; ps < WP; ++ps) {
+            const int u = tid + ps * 256;
+            if (u < WU) *reinterpret_cast<f32x4*>(Ws + (u / UPR) * LDK + kq4) = wr[ps];
+        }
+    };
+
+    f32x4 acc[MT][NT];
+#pragma unroll
+    for (int mi = 0; mi < MT; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NT; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int frow = lane & 15, fk = (lane >> 4) * 4;
+    if (kt_begin < kt_end) load_tile(kt_begin);
+    for (int kt = kt_begin; kt < kt_end; ++kt) {
+        store_tile();
+        __syncthreads();
+        if (kt + 1 < kt_end) load_tile(kt + 1);
+#pragma unroll
+        for (int kc = 0; kc < BK / 16; ++kc) {
+            f32x4 a[NT], b[MT];
+#pragma unroll
+            for (int ni = 0; ni < NT; ++ni)
+                a[ni] = *reinterpret_cast<const f32x4*>(Ws + ((wn * NT + ni) * 16 + frow) * LDK + kc * 16 + fk);
+#pragma unroll
+            for (int mi = 0; mi < MT; ++mi)
+                b[mi] = *reinterpret_cast<const f32x4*>(Xs + ((wm * MT + mi) * 16 + frow) * LDK + kc * 16 + fk);
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+#pragma unroll
+                for (int mi = 0; mi < MT; ++mi)
+#pragma unroll
+                    for (int ni = 0; ni < NT; ++ni)
+                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[ni][s], b[mi][s], acc[mi][ni], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+
+    // ---- epilogue: lane holds out[m = .. + (lane & 15)][n = .. + (lane >> 4) * 4 + 0..3]
+#pragma unroll
+    for (int mi = 0; mi < MT; ++mi) {
+        const long m = m0 + (wm * MT + mi) * 16 + (lane & 15);
+        if (m >= p.M) continue;
+        const int b = (int)(m / HoWo);
+        const long pix = m - (long)b * HoWo;
+        float* orow = p.out + (long)b * p.out_batch_stride + pix * p.out_pixel_stride;
+#pragma unroll
+        for (int ni = 0; ni < NT; ++ni) {
+            const int n = n0 + (wn * NT + ni) * 16 + (lane >> 4) * 4;
+            if (n >= p.Cout) continue;
+            f32x4 v = acc[mi][ni];
+            if (p.split_k > 1) {
+                float* prow = p.partial + ((long)blockIdx.y * p.M + m) * p.Cout + n;
+                if (n + 3 < p.Cout && (p.Cout & 3) == 0) {
+                    *reinterpret_cast<f32x4*>(prow) = v;
+                } else {
+                    for (int j = 0; j < 4; ++j)
+                        if (n + j < p.Cout) prow[j] = v[j];
+                }
+                continue;
+            }
+            if (n + 3 < p.Cout) {
+                if (p.scale) {
+                    const f32x4 sc = *reinterpret_cast<const f32x4*>(p.scale + n);
+                    v = v * sc;
+                }
+                if (p.shift) {
+                    const f32x4 sh = *reinterpret_cast<const f32x4*>(p.shift + n);
+                    v = v + sh;
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] = apply_act(v[j], p.act);
+                if (p.residual) {
+                    const float* rr = p.residual + m * p.Cout + n;
+                    if ((p.Cout & 3) == 0) {
+                        v = v + *reinterpret_cast<const f32x4*>(rr);
+                    } else {
+                        for (int j = 0; j < 4; ++j) v[j] += rr[j];
+                    }
+                }
+                if (p.vec_store) {
+                    *reinterpret_cast<f32x4*>(orow + n) = v;
+                } else {
+                    orow[n] = v[0]; orow[n + 1] = v[1]; orow[n + 2] = v[2]; orow[n + 3] = v[3];
+                }
+            } else {
+                for (int j = 0; j < 4; ++j) {
+                    if (n + j >= p.Cout) break;
+                    float t = v[j];
+                    if (p.scale) t = t * p.scale[n + j];
+                    if (p.shift) t = t + p.shift[n + j];
+                    t = apply_act(t, p.act);
+                    if (p.residual) t += p.residual[m * p.Cout + n + j];
+                    orow[n + j] = t;
+                }
+            }
+        }
+    }
+}
+
+// Split-K reduction + epilogue (deterministic order: s = 0, 1, ...).
+__global__ void splitk_reduce_kernel(const ConvParams p) {
+    const long total = p.M * p.Cout;
+    const int HoWo = p.Ho * p.Wo;
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+        const long m = e / p.Cout;
+        const int n = (int)(e - m * p.Cout);
+        float t = 0.f;
+        for (int s = 0; s < p.split_k; ++s) t += p.partial[(long)s * total + e];
+        if (p.scale) t = t * p.scale[n];
+        if (p.shift) t = t + p.shift[n];
+        t = apply_act(t, p.act);
+        if (p.residual) t += p.residual[e];
+        const int b = (int)(m / HoWo);
+        const long pix = m - (long)b * HoWo;
+        p.out[(long)b * p.out_batch_stride + pix * p.out_pixel_stride + n] = t;
+    }
+}
+
+// VALU direct convolution for the layers the MFMA path cannot take (Cin not a multiple of 4:
+// the RGB stems Conv1 / conv1_1, K = 27).  Weights [K][Cout] staged in LDS; one thread =
+// one pixel x 4 output channels; lanes sharing a pixel broadcast-load the same inputs.
+__global__ __launch_bounds__(256) void conv_direct_kernel(const ConvParams p) {
+    extern __shared__ __attribute__((aligned(16))) float wl[];   // [K][Cout4]
+    const int Cout4 = (p.Cout + 3) & ~3;
+    for (int e = threadIdx.x; e < p.K * Cout4; e += 256) {
+        const int k = e / Cout4, n = e - k * Cout4;
+        wl[e] = n < p.Cout ? p.w[(long)n * p.Kpad + k] : 0.f;
+    }
+    __syncthreads();
+    const int cq_n = Cout4 / 4;
+    const int HoWo = p.Ho * p.Wo;
+    const long total = p.M * cq_n;
+    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+        const long m = e / cq_n;
+        const int n = (int)(e - m * cq_n) * 4;
+        const int b = (int)(m / HoWo);
+        const long pix = m - (long)b * HoWo;
+        const int oy = (int)(pix / p.Wo), ox = (int)(pix - (long)oy * p.Wo);
+        const float* xb = p.in + (long)b * p.H * p.W * p.Cin;
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        for (int ky = 0; ky < p.kh; ++ky) {
+            const int iy = oy * p.stride - p.pad_t + ky * p.dil;
+            if ((unsigned)iy >= (unsigned)p.H) continue;
+            for (int kx = 0; kx < p.kw; ++kx) {
+                const int ix = ox * p.stride - p.pad_l + kx * p.dil;
+                if ((unsigned)ix >= (unsigned)p.W) continue;
+                const float* xp = xb + ((long)iy * p.W + ix) * p.Cin;
+                const float* wp = wl + (ky * p.kw + kx) * p.Cin * Cout4 + n;
+                for (int ci = 0; ci < p.Cin; ++ci) {
+                    const float x = xp[ci];
+                    const f32x4 w4 = *reinterpret_cast<const f32x4*>(wp + ci * Cout4);
+                    acc[0] = fmaf(x, w4[0], acc[0]);
+                    acc[1] = fmaf(x, w4[1], acc[1]);
+                    acc[2] = fmaf(x, w4[2], acc[2]);
+                    acc[3] = fmaf(x, w4[3], acc[3]);
+                }
+            }
+        }
+        float* orow = p.out + (long)b * p.out_batch_stride + pix * p.out_pixel_stride;
+        for (int j = 0; j < 4; ++j) {
+            if (n + j >= p.Cout) break;
+            float t = acc[j];
+            if (p.scale) t = t * p.scale[n + j];
+            if (p.shift) t = t + p.shift[n + j];
+            t = apply_act(t, p.act);
+            if (p.residual) t += p.residual[m * p.Cout + n + j];
+            orow[n + j] = t;
+        }
+    }
+}
+
+// HWIO [K][Cout] -> packed [Npad][Kpad], zero padded.
+__global__ void pack_weights_kernel(const float* __restrict__ hwio, int K, int Cout, int Kpad, int Npad,
+                                    float* __restrict__ packed) {
+    const long total = (long)Npad * Kpad;
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+        const int n = (int)(e / Kpad), k = (int)(e - (long)n * Kpad);
+        packed[e] = (n < Cout && k < K) ? hwio[(long)k * Cout + n] : 0.f;
+    }
+}
+
+// ------------------------------------------------------------------ config table
+typedef void (*conv_kernel_t)(const ConvParams);
+struct ConvCfg {
+    const char* name;
+    int BM, BN, BK;
+    conv_kernel_t gemm, general;
+};
+#define CFG(MT, NT, WM, WN, BK)                                                            \
+    {"mfma_" #MT "x" #NT "_" #WM "x" #WN "_k" #BK, 16 * MT * WM, 16 * NT * WN, BK,          \
+     conv_mfma_kernel<MT, NT, WM, WN, BK, true>, conv_mfma_kernel<MT, NT, WM, WN, BK, false>}
+static const ConvCfg kCfgs[] = {
+    CFG(2, 1, 4, 1, 32),   // 0: 128 x 16
+    CFG(2, 2, 4, 1, 32),   // 1: 128 x 32
+    CFG(2, 4, 4, 1, 32),   // 2: 128 x 64
+    CFG(2, 6, 4, 1, 32),   // 3: 128 x 96
+    CFG(2, 4, 2, 2, 32),   // 4: 64 x 128
+    CFG(1, 2, 2, 2, 32),   // 5: 32 x 64
+    CFG(4, 4, 2, 2, 32),   // 6: 128 x 128
+    CFG(1, 1, 4, 1, 32),   // 7: 64 x 16
+    CFG(2, 9, 4, 1, 32),   // 8: 128 x 144
+    CFG(2, 12, 4, 1, 32),  // 9: 128 x 192
+    CFG(1, 4, 1, 4, 32),   // 10: 16 x 256
+    CFG(2, 2, 2, 2, 32),   // 11: 64 x 64
+    CFG(2, 6, 4, 1, 16),   // 12: 128 x 96, BK 16 (K = 16 expand layers)
+    CFG(1, 2, 1, 4, 32),   // 13: 16 x 128
+    CFG(4, 2, 4, 1, 32),   // 14: 256 x 32
+    CFG(2, 8, 2, 2, 32),   // 15: 64 x 256
+};
+constexpr int kNumMfmaCfgs = sizeof(kCfgs) / sizeof(kCfgs[0]);
+constexpr int kDirectCfg = kNumMfmaCfgs;       // last config id = VALU direct kernel
+
+int conv_num_configs() { return kNumMfmaCfgs + 1; }
+const char* conv_config_name(int cfg) {
+    if (cfg == kDirectCfg) return "direct_valu";
+    if (cfg < 0 || cfg >= kNumMfmaCfgs) return "?";
+    return kCfgs[cfg].name;
+}
+
+static bool is_gemm1x1(const ConvParams& p) {
+    return p.kh == 1 && p.kw == 1 && p.stride == 1 && p.pad_t == 0 && p.pad_l == 0 && p.Ho == p.H && p.Wo == p.W;
+}
+
+bool conv_config_valid(int cfg, const ConvParams& p) {
+    if (cfg == kDirectCfg) return (size_t)p.K * ((p.Cout + 3) & ~3) * 4 <= 64 * 1024;
+    if (cfg < 0 || cfg >= kNumMfmaCfgs) return false;
+    if (((uintptr_t)p.in & 15) || ((uintptr_t)p.w & 15)) return false;
+    if (p.Cin % 4) return false;
+    if (is_gemm1x1(p)) return true;
+    return p.Cin % kCfgs[cfg].BK == 0;
+}
+
+// Cost model used when no autotuned choice is supplied: MFMA time of the padded tiles on
+// 256 CUs vs the L2->LDS operand traffic; the smaller estimate wins.
+int conv_pick_config(const ConvParams& p) {
+    int best = -1;
+    double best_cost = 1e300;
+    for (int c = 0; c < kNumMfmaCfgs; ++c) {
+        if (!conv_config_valid(c, p)) continue;
+        const ConvCfg& g = kCfgs[c];
+        const double mb = (double)((p.M + g.BM - 1) / g.BM), nb = (double)((p.Cout + g.BN - 1) / g.BN);
+        const double kk = (double)round_up(p.K, g.BK);
+        const double blocks = mb * nb;
+        const double waves = ceil(blocks / 256.0);
+        const double t_mfma = waves * (double)g.BM * g.BN * kk * 2.0 / (157.3e12 / 256.0);
+        const double bytes = (mb * g.BM * kk * nb + nb * g.BN * kk * mb) * 4.0 + (double)p.M * p.Cout * 4.0;
+        const double t_mem = bytes / 6.0e12;
+        const double cost = (t_mfma > t_mem ? t_mfma : t_mem) + 0.25 * (t_mfma < t_mem ? t_mfma : t_mem);
+        if (cost < best_cost) { best_cost = cost; best = c; }
+    }
+    if (best < 0 && conv_config_valid(kDirectCfg, p)) best = kDirectCfg;
+    return best;
+}
+
+size_t conv_splitk_workspace_floats(const ConvParams& p, int) {
+    return p.split_k > 1 ? (size_t)p.split_k * p.M * p.Cout : 0;
+}
+
+int conv_launch(const ConvParams& p, int cfg, hipStream_t st) {
+    if (p.M == 0 || p.Cout == 0) return SSD_OK;
+    if (!conv_config_valid(cfg, p)) {
+        set_error("conv2d: config %d (%s) cannot run Cin=%d k=%dx%d stride=%d", cfg, conv_config_name(cfg),
+                  p.Cin, p.kh, p.kw, p.stride);
+        return SSD_E_UNSUPPORTED;
+    }
+    if (cfg == kDirectCfg) {
+        const long total = p.M * ((p.Cout + 3) / 4);
+        const int blocks = (int)(cdiv(total, 256) < 8192 ? cdiv(total, 256) : 8192);
+        const size_t lds = (size_t)p.K * ((p.Cout + 3) & ~3) * 4;
+        hipLaunchKernelGGL(conv_direct_kernel, dim3(blocks), dim3(256), lds, st, p);
+        SSD_LAUNCH_CHECK();
+        return SSD_OK;
+    }
+    const ConvCfg& g = kCfgs[cfg];
+    const long mb = (p.M + g.BM - 1) / g.BM;
+    const int nb = (p.Cout + g.BN - 1) / g.BN;
+    SSD_UNSUPPORTED_IF(mb * nb > 0x7fffffffL, "conv2d: grid too large");
+    dim3 grid((unsigned)(mb * nb), p.split_k > 1 ? p.split_k : 1);
+    conv_kernel_t k = is_gemm1x1(p) ? g.gemm : g.general;
+    hipLaunchKernelGGL(k, grid, dim3(256), 0, st, p);
+    SSD_LAUNCH_CHECK();
+    if (p.split_k > 1) {
+        const long total = p.M * p.Cout;
+        const int blocks = (int)(cdiv(total, 256) < 4096 ? cdiv(total, 256) : 4096);
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, st, p);
+        SSD_LAUNCH_CHECK();
+    }
+    return SSD_OK;
+}
+
+int launch_pack_weights(const float* hwio, int K, int Cout, int Kpad, int Npad, float* packed, hipStream_t st) {
+    const long total = (long)Npad * Kpad;
+    if (total == 0) return SSD_OK;
+    const int blocks = (int)(cdiv(total, 256) < 4096 ? cdiv(total, 256) : 4096);
+    hipLaunchKernelGGL(pack_weights_kernel, dim3(blocks), dim3(256), 0, st, hwio, K, Cout, Kpad, Npad, packed);
+    SSD_LAUNCH_CHECK();
+    return SSD_OK;
+}
+
+int fill_conv_params(const ssd_conv_desc* d, ConvParams* p) {
+    SSD_CHECK_ARG(d != nullptr, "conv2d: descriptor is NULL");
+    SSD_CHECK_ARG(d->B >= 0 && d->H >= 1 && d->W >= 1 && d->Cin >= 1 && d->Cout >= 1,
+                  "conv2d: bad tensor sizes B=%d H=%d W=%d Cin=%d Cout=%d", d->B, d->H, d->W, d->Cin, d->Cout);
+    SSD_CHECK_ARG(d->kh >= 1 && d->kw >= 1 && d->stride >= 1 && d->dilation >= 1,
+                  "conv2d: bad kernel %dx%d stride %d dilation %d", d->kh, d->kw, d->stride, d->dilation);
+    SSD_CHECK_ARG(d->pad_t >= 0 && d->pad_l >= 0 && d->pad_b >= 0 && d->pad_r >= 0, "conv2d: negative padding");
+    SSD_CHECK_ARG(d->act >= 0 && d->act <= 2, "conv2d: unknown activation %d", d->act);
+    const int Ho = ssd_conv_out_size(d->H, d->kh, d->stride, d->dilation, d->pad_t, d->pad_b);
+    const int Wo = ssd_conv_out_size(d->W, d->kw, d->stride, d->dilation, d->pad_l, d->pad_r);
+    SSD_CHECK_ARG(Ho >= 1 && Wo >= 1, "conv2d: empty output (%d x %d)", Ho, Wo);
+    *p = ConvParams{};
+    p->B = d->B; p->H = d->H; p->W = d->W; p->Cin = d->Cin; p->Ho = Ho; p->Wo = Wo; p->Cout = d->Cout;
+    p->kh = d->kh; p->kw = d->kw; p->stride = d->stride; p->dil = d->dilation;
+    p->pad_t = d->pad_t; p->pad_l = d->pad_l;
+    p->K = d->kh * d->kw * d->Cin;
+    p->Kpad = conv_kpad(p->K);
+    p->Npad = conv_npad(d->Cout);
+    p->M = (long)d->B * Ho * Wo;
+    p->act = d->act;
+    p->split_k = 1;
+    return SSD_OK;
+}
+
+}  // namespace ssd
+
+using namespace ssd;
+
+extern "C" {
+
+int ssd_same_pads(int in, int k, int stride, int dilation, int* before, int* after) {
+    if (in < 1 || k < 1 || stride < 1 || dilation < 1) return SSD_E_INVALID;
+    const int out = (in + stride - 1) / stride;
+    const int keff = (k - 1) * dilation + 1;
+    int p = (out - 1) * stride + keff - in;
+    if (p < 0) p = 0;
+    if (before) *before = p / 2;
+    if (after) *after = p - p / 2;
+    return out;
+}
+
+int ssd_conv_out_size(int in, int k, int stride, int dilation, int pad_before, int pad_after) {
+    if (in < 1 || k < 1 || stride < 1 || dilation < 1) return 0;
+    const int keff = (k - 1) * dilation + 1;
+    const int span = in + pad_before + pad_after - keff;
+    if (span < 0) return 0;
+    return span / stride + 1;
+}
+
+size_t ssd_conv_packed_weight_floats(int kh, int kw, int Cin, int Cout) {
+    if (kh < 1 || kw < 1 || Cin < 1 || Cout < 1) return 0;
+    return (size_t)conv_kpad(kh * kw * Cin) * conv_npad(Cout);
+}
+
+int ssd_conv_pack_weights(const float* hwio_dev, int kh, int kw, int Cin, int Cout, float* packed_dev,
+                          void* stream) {
+    SSD_CHECK_ARG(hwio_dev && packed_dev, "ssd_conv_pack_weights: NULL pointer");
+    SSD_CHECK_ARG(kh >= 1 && kw >= 1 && Cin >= 1 && Cout >= 1, "ssd_conv_pack_weights: bad shape");
+    const int K = kh * kw * Cin;
+    return launch_pack_weights(hwio_dev, K, Cout, conv_kpad(K), conv_npad(Cout), packed_dev, (hipStream_t)stream);
+}
+
+int ssd_conv_num_configs(void) { return conv_num_configs(); }
+const char* ssd_conv_config_name(int cfg) { return conv_config_name(cfg); }
+
+int ssd_conv2d_ex(const ssd_conv_desc* d, const float* in_dev, const float* packed_w_dev,
+                  const float* scale_dev, const float* shift_dev, const float* residual_dev, float* out_dev,
+                  long out_batch_stride, long out_pixel_stride, int config, int split_k,
+                  float* splitk_ws_dev, void* stream) {
+    ConvParams p;
+    int rc = fill_conv_params(d, &p);
+    if (rc) return rc;
+    if (p.M == 0) return SSD_OK;
+    SSD_CHECK_ARG(in_dev && packed_w_dev && out_dev, "conv2d: NULL pointer");
+    SSD_CHECK_ARG(!d->has_residual || residual_dev, "conv2d: has_residual set but residual is NULL");
+    p.in = in_dev; p.w = packed_w_dev; p.scale = scale_dev; p.shift = shift_dev;
+    p.residual = d->has_residual ? residual_dev : nullptr;
+    p.out = out_dev;
+    p.out_pixel_stride = out_pixel_stride > 0 ? out_pixel_stride : p.Cout;
+    p.out_batch_stride = out_batch_stride > 0 ? out_batch_stride : (long)p.Ho * p.Wo * p.out_pixel_stride;
+    p.vec_store = (((uintptr_t)out_dev & 15) == 0) && (p.out_pixel_stride % 4 == 0) && (p.out_batch_stride % 4 == 0);
+    if (split_k > 1) {
+        SSD_CHECK_ARG(splitk_ws_dev != nullptr, "conv2d: split_k > 1 needs a workspace");
+        p.split_k = split_k;
+        p.partial = splitk_ws_dev;
+    }
+    const int cfg = config >= 0 ? config : conv_pick_config(p);
+    SSD_UNSUPPORTED_IF(cfg < 0, "conv2d: no kernel for Cin=%d Cout=%d k=%dx%d", p.Cin, p.Cout, p.kh, p.kw);
+    if (cfg == conv_num_configs() - 1) p.split_k = 1;
+    return conv_launch(p, cfg, (hipStream_t)stream);
+}
+
+int ssd_conv2d(const ssd_conv_desc* d, const float* in_dev, const float* packed_w_dev, const float* scale_dev,
+               const float* shift_dev, const float* residual_dev, float* out_dev, long out_batch_stride,
+               long out_pixel_stride, void* stream) {
+    return ssd_conv2d_ex(d, in_dev, packed_w_dev, scale_dev, shift_dev, residual_dev, out_dev,
+                         out_batch_stride, out_pixel_stride, -1, 1, nullptr, stream);
+}
+
+}  // extern "C"

@@ -1,0 +1,682 @@
+// Graph runner: builds the SSD300 MobileNetV2 / VGG16 forward graphs natively, owns the
+// parameters (Keras names + layouts at the boundary), folds BatchNorm, packs weights for
+// the MFMA kernels, plans the activation arena in HBM, autotunes the tile configuration of
+// every conv on the device, and replays the layer list on a HIP stream.
+//
+// Reference graphs: models/ssd_mobilenet_v2.py:7-35 (+ [3P] keras-applications 1.0.8
+// MobileNetV2), models/ssd_vgg16.py:33-97, models/header.py:43-67.
+#include <algorithm>
+#include <map>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "ssd_conv.h"
+
+namespace ssd {
+
+enum LayerKind { LK_CONV = 0, LK_DW, LK_POOL, LK_L2NORM, LK_SOFTMAX };
+static const char* kKindName[] = {"conv", "dw", "pool", "l2norm", "softmax"};
+
+struct Param {
+    std::string name;
+    std::vector<int> shape;
+    size_t count = 0;
+    float* dev = nullptr;
+    bool set = false;
+};
+
+struct Tensor {
+    std::string name;
+    int H = 0, W = 0, C = 0;
+    size_t per_image = 0;     // floats
+    float* dev = nullptr;     // arena slot, max_batch images
+};
+
+struct Layer {
+    std::string name;
+    LayerKind kind = LK_CONV;
+    int in = -1, out = -1, res = -1;          // tensor ids (out == -1: head conv -> net outputs)
+    int H = 0, W = 0, Cin = 0, Ho = 0, Wo = 0, Cout = 0;
+    int kh = 1, kw = 1, stride = 1, dil = 1, pt = 0, pl = 0, pb = 0, pr = 0, act = 0;
+    int p_kernel = -1, p_bias = -1, p_bn = -1;  // p_bn: index of gamma (beta, mean, var follow)
+    int p_gamma = -1;                           // l2norm scale
+    // head routing (floats): level offset, batch stride, pixel stride; head_kind 1 = labels, 2 = boxes
+    int head_kind = 0;
+    long head_off = 0, head_bs = 0, head_ps = 0;
+    // derived at finalize
+    float* packed = nullptr;
+    float* scale = nullptr;
+    float* shift = nullptr;
+    int cfg = -1;
+    int split_k = 1;
+};
+
+}  // namespace ssd
+
+using namespace ssd;
+
+struct ssd_net {
+    int backbone = 0, img_size = 300, levels = 6, L = 21;
+    std::vector<int> n_ars;
+    std::vector<Param> params;
+    std::map<std::string, int> param_index;
+    std::vector<Tensor> tensors;
+    std::map<std::string, int> tensor_index;
+    std::vector<Layer> layers;
+    std::vector<int> fmap;          // feature-map size per level
+    std::vector<long> level_off;    // prior offset per level
+    int num_priors = 0;
+    bool finalized = false;
+    int max_batch = 0;
+    int last_batch = 0;
+    std::vector<float*> owned;      // device allocations to free
+    float* arena = nullptr;
+    float* splitk_ws = nullptr;
+    size_t splitk_floats = 0;
+    // predict() scratch
+    float* deltas = nullptr;
+    float* probs = nullptr;
+    void* nms_ws = nullptr;
+    size_t nms_ws_bytes = 0;
+
+    ~ssd_net() {
+        for (auto& p : params)
+            if (p.dev) (void)hipFree(p.dev);
+        for (float* p : owned)
+            if (p) (void)hipFree(p);
+        if (arena) (void)hipFree(arena);
+        if (splitk_ws) (void)hipFree(splitk_ws);
+        if (deltas) (void)hipFree(deltas);
+        if (probs) (void)hipFree(probs);
+        if (nms_ws) (void)hipFree(nms_ws);
+    }
+};
+
+namespace ssd {
+
+// ------------------------------------------------------------------ graph builder
+struct Builder {
+    ssd_net& net;
+    explicit Builder(ssd_net& n) : net(n) {}
+
+    int add_param(const std::string& name, std::vector<int> shape) {
+        Param p;
+        p.name = name;
+        p.shape = std::move(shape);
+        p.count = 1;
+        for (int d : p.shape) p.count *= (size_t)d;
+        net.params.push_back(p);
+        net.param_index[name] = (int)net.params.size() - 1;
+        return (int)net.params.size() - 1;
+    }
+    int add_bn(const std::string& name, int c) {
+        const int g = add_param(name + "/gamma", {c});
+        add_param(name + "/beta", {c});
+        add_param(name + "/moving_mean", {c});
+        add_param(name + "/moving_variance", {c});
+        return g;
+    }
+    int add_tensor(const std::string& name, int H, int W, int C) {
+        Tensor t;
+        t.name = name;
+        t.H = H; t.W = W; t.C = C;
+        t.per_image = (size_t)H * W * C;
+        net.tensors.push_back(t);
+        net.tensor_index[name] = (int)net.tensors.size() - 1;
+        return (int)net.tensors.size() - 1;
+    }
+    // pad_mode: 0 valid, 1 same, 2 keras correct_pad (ZeroPadding2D before a stride-2 VALID conv)
+    void pads(int in, int k, int stride, int dil, int mode, int* before, int* after) {
+        *before = *after = 0;
+        if (mode == 1) {
+            ssd_same_pads(in, k, stride, dil, before, after);
+        } else if (mode == 2) {
+            const int adjust = 1 - in % 2, correct = k / 2;      // [3P] keras-applications correct_pad
+            *before = correct - adjust;
+            *after = correct;
+        }
+    }
+    // Conv2D [+BN | +bias] +act [+residual].  Returns the output tensor id.
+    int conv(const std::string& name, const std::string& out_name, int in, int Cout, int k, int stride,
+             int pad_mode, int dil, const std::string& bn_name, bool bias, int act, int res = -1) {
+        const Tensor ti = net.tensors[in];
+        Layer l;
+        l.name = name;
+        l.kind = LK_CONV;
+        l.in = in; l.res = res;
+        l.H = ti.H; l.W = ti.W; l.Cin = ti.C; l.Cout = Cout;
+        l.kh = l.kw = k; l.stride = stride; l.dil = dil; l.act = act;
+        pads(ti.H, k, stride, dil, pad_mode, &l.pt, &l.pb);
+        pads(ti.W, k, stride, dil, pad_mode, &l.pl, &l.pr);
+        l.Ho = ssd_conv_out_size(ti.H, k, stride, dil, l.pt, l.pb);
+        l.Wo = ssd_conv_out_size(ti.W, k, stride, dil, l.pl, l.pr);
+        l.p_kernel = add_param(name + "/kernel", {k, k, ti.C, Cout});
+        if (bias) l.p_bias = add_param(name + "/bias", {Cout});
+        if (!bn_name.empty()) l.p_bn = add_bn(bn_name, Cout);
+        if (!out_name.empty()) l.out = add_tensor(out_name, l.Ho, l.Wo, Cout);
+        net.layers.push_back(l);
+        return l.out;
+    }
+    int dwconv(const std::string& name, const std::string& out_name, int in, int stride, int pad_mode,
+               const std::string& bn_name, int act) {
+        const Tensor ti = net.tensors[in];
+        Layer l;
+        l.name = name;
+        l.kind = LK_DW;
+        l.in = in;
+        l.H = ti.H; l.W = ti.W; l.Cin = l.Cout = ti.C;
+        l.kh = l.kw = 3; l.stride = stride; l.act = act;
+        pads(ti.H, 3, stride, 1, pad_mode, &l.pt, &l.pb);
+        pads(ti.W, 3, stride, 1, pad_mode, &l.pl, &l.pr);
+        l.Ho = ssd_conv_out_size(ti.H, 3, stride, 1, l.pt, l.pb);
+        l.Wo = ssd_conv_out_size(ti.W, 3, stride, 1, l.pl, l.pr);
+        l.p_kernel = add_param(name + "/depthwise_kernel", {3, 3, ti.C, 1});
+        l.p_bn = add_bn(bn_name, ti.C);
+        l.out = add_tensor(out_name, l.Ho, l.Wo, ti.C);
+        net.layers.push_back(l);
+        return l.out;
+    }
+    int pool(const std::string& name, int in, int k, int stride) {
+        const Tensor ti = net.tensors[in];
+        Layer l;
+        l.name = name;
+        l.kind = LK_POOL;
+        l.in = in;
+        l.H = ti.H; l.W = ti.W; l.Cin = l.Cout = ti.C;
+        l.kh = l.kw = k; l.stride = stride;
+        pads(ti.H, k, stride, 1, 1, &l.pt, &l.pb);
+        pads(ti.W, k, stride, 1, 1, &l.pl, &l.pr);
+        l.Ho = ssd_conv_out_size(ti.H, k, stride, 1, l.pt, l.pb);
+        l.Wo = ssd_conv_out_size(ti.W, k, stride, 1, l.pl, l.pr);
+        l.out = add_tensor(name, l.Ho, l.Wo, ti.C);
+        net.layers.push_back(l);
+        return l.out;
+    }
+    // models/header.py:43-67: per level a label conv (A*L) and a box conv (A*4), 3x3 SAME, bias.
+    void heads(const std::vector<int>& feats) {
+        long off = 0;
+        net.fmap.clear();
+        net.level_off.clear();
+        for (size_t i = 0; i < feats.size(); ++i) {
+            const Tensor t = net.tensors[feats[i]];
+            net.fmap.push_back(t.H);
+            net.level_off.push_back(off);
+            off += (long)t.H * t.W * (net.n_ars[i] + 1);
+        }
+        net.num_priors = (int)off;
+        for (size_t i = 0; i < feats.size(); ++i) {
+            const int A = net.n_ars[i] + 1;
+            const std::string idx = std::to_string(i + 1);
+            for (int which = 1; which <= 2; ++which) {
+                const int comp = which == 1 ? net.L : 4;
+                conv(idx + (which == 1 ? "_conv_label_output" : "_conv_boxes_output"), "", feats[i], A * comp,
+                     3, 1, 1, 1, "", true, SSD_ACT_NONE);
+                Layer& l = net.layers.back();
+                l.head_kind = which;
+                l.head_off = net.level_off[i] * comp;
+                l.head_bs = (long)net.num_priors * comp;
+                l.head_ps = (long)A * comp;
+            }
+        }
+        Layer sm;
+        sm.name = "conf";
+        sm.kind = LK_SOFTMAX;
+        sm.Cout = net.L;
+        net.layers.push_back(sm);
+    }
+};
+
+static void build_mobilenet_v2(ssd_net& net) {
+    Builder b(net);
+    const int S = net.img_size;
+    int x = b.add_tensor("input", S, S, 3);
+    x = b.conv("Conv1", "Conv1_relu", x, 32, 3, 2, 2, 1, "bn_Conv1", false, SSD_ACT_RELU6);
+    x = b.dwconv("expanded_conv_depthwise", "expanded_conv_depthwise_relu", x, 1, 1, "expanded_conv_depthwise_BN",
+                 SSD_ACT_RELU6);
+    x = b.conv("expanded_conv_project", "expanded_conv_project_BN", x, 16, 1, 1, 1, 1, "expanded_conv_project_BN",
+               false, SSD_ACT_NONE);
+    static const int blocks[16][2] = {{24, 2}, {24, 1}, {32, 2}, {32, 1}, {32, 1}, {64, 2}, {64, 1}, {64, 1},
+                                      {64, 1}, {96, 1}, {96, 1}, {96, 1}, {160, 2}, {160, 1}, {160, 1}, {320, 1}};
+    int cin = 16, tap1 = -1;
+    for (int k = 1; k <= 16; ++k) {
+        const int cout = blocks[k - 1][0], s = blocks[k - 1][1];
+        const std::string p = "block_" + std::to_string(k) + "_";
+        const int inp = x;
+        x = b.conv(p + "expand", p + "expand_relu", x, 6 * cin, 1, 1, 1, 1, p + "expand_BN", false, SSD_ACT_RELU6);
+        if (k == 13) tap1 = x;       // block_13_expand_relu (models/ssd_mobilenet_v2.py:18)
+        x = b.dwconv(p + "depthwise", p + "depthwise_relu", x, s, s == 2 ? 2 : 1, p + "depthwise_BN", SSD_ACT_RELU6);
+        const bool res = (cin == cout && s == 1);
+        x = b.conv(p + "project", p + "out", x, cout, 1, 1, 1, 1, p + "project_BN", false, SSD_ACT_NONE,
+                   res ? inp : -1);
+        cin = cout;
+    }
+    x = b.conv("Conv_1", "out_relu", x, 1280, 1, 1, 1, 1, "Conv_1_bn", false, SSD_ACT_RELU6);
+    std::vector<int> feats = {tap1, x};
+    static const int extras[4][2] = {{256, 512}, {128, 256}, {128, 256}, {128, 256}};
+    for (int i = 1; i <= 4; ++i) {
+        const std::string e = "extra" + std::to_string(i);
+        x = b.conv(e + "_1", e + "_1", x, extras[i - 1][0], 1, 1, 0, 1, "", true, SSD_ACT_RELU);
+        x = b.conv(e + "_2", e + "_2", x, extras[i - 1][1], 3, 2, 1, 1, "", true, SSD_ACT_RELU);
+        feats.push_back(x);
+    }
+    b.heads(feats);
+}
+
+static void build_vgg16(ssd_net& net) {
+    Builder b(net);
+    const int S = net.img_size;
+    int x = b.add_tensor("input", S, S, 3);
+    auto c3 = [&](const char* name, int cout) { x = b.conv(name, name, x, cout, 3, 1, 1, 1, "", true, SSD_ACT_RELU); };
+    c3("conv1_1", 64); c3("conv1_2", 64); x = b.pool("pool1", x, 2, 2);
+    c3("conv2_1", 128); c3("conv2_2", 128); x = b.pool("pool2", x, 2, 2);
+    c3("conv3_1", 256); c3("conv3_2", 256); c3("conv3_3", 256); x = b.pool("pool3", x, 2, 2);
+    c3("conv4_1", 512); c3("conv4_2", 512); c3("conv4_3", 512);
+    const int conv4_3 = x;
+    x = b.pool("pool4", x, 2, 2);
+    c3("conv5_1", 512); c3("conv5_2", 512); c3("conv5_3", 512); x = b.pool("pool5", x, 3, 1);
+    x = b.conv("conv6", "conv6", x, 1024, 3, 1, 1, 6, "", true, SSD_ACT_RELU);
+    x = b.conv("conv7", "conv7", x, 1024, 1, 1, 1, 1, "", true, SSD_ACT_RELU);
+    const int conv7 = x;
+    x = b.conv("conv8_1", "conv8_1", x, 256, 1, 1, 0, 1, "", true, SSD_ACT_RELU);
+    x = b.conv("conv8_2", "conv8_2", x, 512, 3, 2, 1, 1, "", true, SSD_ACT_RELU);
+    const int conv8_2 = x;
+    x = b.conv("conv9_1", "conv9_1", x, 128, 1, 1, 0, 1, "", true, SSD_ACT_RELU);
+    x = b.conv("conv9_2", "conv9_2", x, 256, 3, 2, 1, 1, "", true, SSD_ACT_RELU);
+    const int conv9_2 = x;
+    x = b.conv("conv10_1", "conv10_1", x, 128, 1, 1, 0, 1, "", true, SSD_ACT_RELU);
+    x = b.conv("conv10_2", "conv10_2", x, 256, 3, 1, 0, 1, "", true, SSD_ACT_RELU);
+    const int conv10_2 = x;
+    x = b.conv("conv11_1", "conv11_1", x, 128, 1, 1, 0, 1, "", true, SSD_ACT_RELU);
+    x = b.conv("conv11_2", "conv11_2", x, 256, 3, 1, 0, 1, "", true, SSD_ACT_RELU);
+    const int conv11_2 = x;
+    // L2Normalization(20)(conv4_3)  (models/ssd_vgg16.py:94)
+    Layer l;
+    l.name = "l2_normalization";
+    l.kind = LK_L2NORM;
+    l.in = conv4_3;
+    const Tensor t = net.tensors[conv4_3];
+    l.H = l.Ho = t.H; l.W = l.Wo = t.W; l.Cin = l.Cout = t.C;
+    l.p_gamma = b.add_param("l2_normalization/scale", {t.C});
+    l.out = b.add_tensor("l2_normalization", t.H, t.W, t.C);
+    net.layers.push_back(l);
+    b.heads({l.out, conv7, conv8_2, conv9_2, conv10_2, conv11_2});
+}
+
+static ConvParams layer_conv_params(const ssd_net& net, const Layer& l, int B, const float* in, float* out,
+                                    const float* res, float* deltas_out, float* probs_out) {
+    ConvParams p{};
+    p.in = in;
+    p.w = l.packed;
+    p.scale = l.scale;
+    p.shift = l.shift;
+    p.residual = res;
+    p.B = B; p.H = l.H; p.W = l.W; p.Cin = l.Cin; p.Ho = l.Ho; p.Wo = l.Wo; p.Cout = l.Cout;
+    p.kh = l.kh; p.kw = l.kw; p.stride = l.stride; p.dil = l.dil; p.pad_t = l.pt; p.pad_l = l.pl;
+    p.K = l.kh * l.kw * l.Cin;
+    p.Kpad = conv_kpad(p.K);
+    p.Npad = conv_npad(l.Cout);
+    p.M = (long)B * l.Ho * l.Wo;
+    p.act = l.act;
+    p.split_k = l.split_k;
+    p.partial = net.splitk_ws;
+    if (l.head_kind == 0) {
+        p.out = out;
+        p.out_pixel_stride = l.Cout;
+        p.out_batch_stride = (long)l.Ho * l.Wo * l.Cout;
+    } else {
+        p.out = (l.head_kind == 1 ? probs_out : deltas_out) + l.head_off;
+        p.out_pixel_stride = l.head_ps;
+        p.out_batch_stride = l.head_bs;
+    }
+    p.vec_store = (((uintptr_t)p.out & 15) == 0) && (p.out_pixel_stride % 4 == 0) && (p.out_batch_stride % 4 == 0);
+    return p;
+}
+
+static int run_layer(ssd_net& net, const Layer& l, int B, float* deltas_out, float* probs_out, hipStream_t st,
+                     int cfg_override = -1) {
+    const float* in = l.in >= 0 ? net.tensors[l.in].dev : nullptr;
+    float* out = l.out >= 0 ? net.tensors[l.out].dev : nullptr;
+    switch (l.kind) {
+        case LK_CONV: {
+            const float* res = l.res >= 0 ? net.tensors[l.res].dev : nullptr;
+            ConvParams p = layer_conv_params(net, l, B, in, out, res, deltas_out, probs_out);
+            return conv_launch(p, cfg_override >= 0 ? cfg_override : l.cfg, st);
+        }
+        case LK_DW:
+            return launch_dwconv3x3(in, B, l.H, l.W, l.Cin, l.stride, l.pt, l.pl, l.Ho, l.Wo,
+                                    net.params[l.p_kernel].dev, l.scale, l.shift, l.act, out, st);
+        case LK_POOL:
+            return launch_maxpool(in, B, l.H, l.W, l.Cin, l.kh, l.stride, l.pt, l.pl, l.Ho, l.Wo, out, st);
+        case LK_L2NORM:
+            return launch_l2norm(in, (long)B * l.H * l.W, l.Cin, net.params[l.p_gamma].dev, out, st);
+        case LK_SOFTMAX:
+            return launch_softmax(probs_out, (long)B * net.num_priors, net.L, probs_out, st);
+    }
+    return SSD_OK;
+}
+
+static int dev_alloc(ssd_net& net, size_t floats, float** out) {
+    *out = nullptr;
+    if (floats == 0) return SSD_OK;
+    SSD_HIP(hipMalloc((void**)out, floats * sizeof(float)));
+    net.owned.push_back(*out);
+    return SSD_OK;
+}
+
+// Time each valid tile configuration of every conv layer on the device and keep the best.
+static int autotune(ssd_net& net, int B, hipStream_t st) {
+    hipEvent_t e0, e1;
+    SSD_HIP(hipEventCreate(&e0));
+    SSD_HIP(hipEventCreate(&e1));
+    // scratch outputs for head convs
+    float *d = nullptr, *pr = nullptr;
+    SSD_HIP(hipMalloc((void**)&d, (size_t)B * net.num_priors * 4 * sizeof(float)));
+    SSD_HIP(hipMalloc((void**)&pr, (size_t)B * net.num_priors * net.L * sizeof(float)));
+    int rc = SSD_OK;
+    for (auto& l : net.layers) {
+        if (l.kind != LK_CONV) continue;
+        const float* in = net.tensors[l.in].dev;
+        float* out = l.out >= 0 ? net.tensors[l.out].dev : nullptr;
+        const float* res = l.res >= 0 ? net.tensors[l.res].dev : nullptr;
+        ConvParams p = layer_conv_params(net, l, B, in, out, res, d, pr);
+        float best = 1e30f;
+        int best_cfg = -1;
+        for (int c = 0; c < conv_num_configs(); ++c) {
+            if (!conv_config_valid(c, p)) continue;
+            if (c == conv_num_configs() - 1 && best_cfg >= 0) continue;   // direct only as a last resort
+            const int reps = 3;
+            rc = conv_launch(p, c, st);     // warm-up
+            if (rc) break;
+            (void)hipEventRecord(e0, st);
+            for (int r = 0; r < reps && !rc; ++r) rc = conv_launch(p, c, st);
+            (void)hipEventRecord(e1, st);
+            if (rc) break;
+            SSD_HIP(hipEventSynchronize(e1));
+            float ms = 0.f;
+            (void)hipEventElapsedTime(&ms, e0, e1);
+            if (ms < best) { best = ms; best_cfg = c; }
+        }
+        if (rc) break;
+        if (best_cfg < 0) {
+            set_error("finalize: no conv kernel can run layer %s", l.name.c_str());
+            rc = SSD_E_UNSUPPORTED;
+            break;
+        }
+        l.cfg = best_cfg;
+    }
+    (void)hipFree(d);
+    (void)hipFree(pr);
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    return rc;
+}
+
+}  // namespace ssd
+
+extern "C" {
+
+ssd_net* ssd_net_create(int backbone, int img_size, int levels, const int* n_ars, int total_labels) {
+    if ((backbone != SSD_MOBILENET_V2 && backbone != SSD_VGG16) || img_size < 32 || levels != 6 || !n_ars ||
+        total_labels < 1) {
+        set_error("ssd_net_create: bad arguments (backbone=%d img_size=%d levels=%d labels=%d)", backbone, img_size,
+                  levels, total_labels);
+        return nullptr;
+    }
+    auto net = std::make_unique<ssd_net>();
+    net->backbone = backbone;
+    net->img_size = img_size;
+    net->levels = levels;
+    net->L = total_labels;
+    net->n_ars.assign(n_ars, n_ars + levels);
+    for (int a : net->n_ars)
+        if (a < 0 || a > 15) {
+            set_error("ssd_net_create: bad aspect-ratio count %d", a);
+            return nullptr;
+        }
+    if (backbone == SSD_MOBILENET_V2) build_mobilenet_v2(*net);
+    else build_vgg16(*net);
+    return net.release();
+}
+
+void ssd_net_destroy(ssd_net* net) { delete net; }
+
+int ssd_net_num_params(const ssd_net* net) { return net ? (int)net->params.size() : 0; }
+const char* ssd_net_param_name(const ssd_net* net, int i) {
+    return (net && i >= 0 && i < (int)net->params.size()) ? net->params[i].name.c_str() : "";
+}
+int ssd_net_param_rank(const ssd_net* net, int i) {
+    return (net && i >= 0 && i < (int)net->params.size()) ? (int)net->params[i].shape.size() : 0;
+}
+const int* ssd_net_param_shape(const ssd_net* net, int i) {
+    return (net && i >= 0 && i < (int)net->params.size()) ? net->params[i].shape.data() : nullptr;
+}
+
+int ssd_net_set_param(ssd_net* net, const char* name, const float* host_data, size_t count) {
+    SSD_CHECK_ARG(net && name && host_data, "ssd_net_set_param: NULL argument");
+    auto it = net->param_index.find(name);
+    SSD_CHECK_ARG(it != net->param_index.end(), "ssd_net_set_param: unknown parameter '%s'", name);
+    Param& p = net->params[it->second];
+    SSD_CHECK_ARG(count == p.count, "ssd_net_set_param: '%s' expects %zu values, got %zu", name, p.count, count);
+    if (!p.dev) SSD_HIP(hipMalloc((void**)&p.dev, p.count * sizeof(float)));
+    SSD_HIP(hipMemcpy(p.dev, host_data, p.count * sizeof(float), hipMemcpyHostToDevice));
+    p.set = true;
+    net->finalized = false;
+    return SSD_OK;
+}
+
+int ssd_net_get_param(const ssd_net* net, const char* name, float* host_out, size_t count) {
+    SSD_CHECK_ARG(net && name && host_out, "ssd_net_get_param: NULL argument");
+    auto it = net->param_index.find(name);
+    SSD_CHECK_ARG(it != net->param_index.end(), "ssd_net_get_param: unknown parameter '%s'", name);
+    const Param& p = net->params[it->second];
+    SSD_CHECK_ARG(count == p.count, "ssd_net_get_param: '%s' holds %zu values, asked %zu", name, p.count, count);
+    if (!p.set) {
+        set_error("ssd_net_get_param: '%s' was never set", name);
+        return SSD_E_STATE;
+    }
+    SSD_HIP(hipMemcpy(host_out, p.dev, p.count * sizeof(float), hipMemcpyDeviceToHost));
+    return SSD_OK;
+}
+
+int ssd_net_finalize(ssd_net* net, int max_batch) {
+    SSD_CHECK_ARG(net && max_batch >= 1, "ssd_net_finalize: bad arguments");
+    for (const auto& p : net->params)
+        if (!p.set) {
+            set_error("ssd_net_finalize: parameter '%s' was never set", p.name.c_str());
+            return SSD_E_STATE;
+        }
+    hipStream_t st = nullptr;
+    // (re)build derived weights
+    for (float* p : net->owned)
+        if (p) (void)hipFree(p);
+    net->owned.clear();
+    for (auto& l : net->layers) {
+        l.packed = l.scale = l.shift = nullptr;
+        if (l.kind == LK_CONV) {
+            const int K = l.kh * l.kw * l.Cin;
+            int rc = dev_alloc(*net, (size_t)conv_kpad(K) * conv_npad(l.Cout), &l.packed);
+            if (rc) return rc;
+            rc = launch_pack_weights(net->params[l.p_kernel].dev, K, l.Cout, conv_kpad(K), conv_npad(l.Cout),
+                                     l.packed, st);
+            if (rc) return rc;
+        }
+        if (l.kind == LK_CONV || l.kind == LK_DW) {
+            if (l.p_bn >= 0) {
+                int rc = dev_alloc(*net, l.Cout, &l.scale);
+                if (!rc) rc = dev_alloc(*net, l.Cout, &l.shift);
+                if (rc) return rc;
+                rc = launch_fold_bn(net->params[l.p_bn].dev, net->params[l.p_bn + 1].dev, net->params[l.p_bn + 2].dev,
+                                    net->params[l.p_bn + 3].dev, 1e-3f, l.Cout, l.scale, l.shift, st);
+                if (rc) return rc;
+            } else if (l.p_bias >= 0) {
+                l.shift = net->params[l.p_bias].dev;     // bias-only epilogue: scale == 1
+            }
+        }
+    }
+    // activation arena: one slot per tensor (288 GB of HBM: no aliasing needed, every
+    // activation of the last forward stays inspectable)
+    if (net->arena) (void)hipFree(net->arena);
+    net->arena = nullptr;
+    size_t total = 0;
+    for (auto& t : net->tensors) total += align_up(t.per_image * max_batch, 64);
+    SSD_HIP(hipMalloc((void**)&net->arena, total * sizeof(float)));
+    size_t off = 0;
+    for (auto& t : net->tensors) {
+        t.dev = net->arena + off;
+        off += align_up(t.per_image * max_batch, 64);
+    }
+    SSD_HIP(hipMemset(net->arena, 0, total * sizeof(float)));
+    net->max_batch = max_batch;
+    // pick tile configurations on the device
+    for (auto& l : net->layers) { l.cfg = -1; l.split_k = 1; }
+    int rc = autotune(*net, max_batch, st);
+    if (rc) return rc;
+    SSD_HIP(hipDeviceSynchronize());
+    net->finalized = true;
+    return SSD_OK;
+}
+
+int ssd_net_num_priors(const ssd_net* net) { return net ? net->num_priors : 0; }
+int ssd_net_feature_map_size(const ssd_net* net, int level) {
+    return (net && level >= 0 && level < (int)net->fmap.size()) ? net->fmap[level] : 0;
+}
+
+static int forward_impl(ssd_net* net, const float* image_dev, int B, float* deltas_out, float* probs_out,
+                        hipStream_t st) {
+    SSD_CHECK_ARG(net != nullptr, "ssd_net_forward: net is NULL");
+    if (!net->finalized) {
+        set_error("ssd_net_forward: call ssd_net_finalize() first");
+        return SSD_E_STATE;
+    }
+    SSD_CHECK_ARG(B >= 0 && B <= net->max_batch, "ssd_net_forward: batch %d exceeds max_batch %d", B, net->max_batch);
+    if (B == 0) return SSD_OK;
+    SSD_CHECK_ARG(image_dev && deltas_out && probs_out, "ssd_net_forward: NULL pointer");
+    SSD_CHECK_ARG(((uintptr_t)deltas_out & 15) == 0 && ((uintptr_t)probs_out & 15) == 0,
+                  "ssd_net_forward: outputs must be 16-byte aligned");
+    // the input tensor aliases the caller's image buffer (no copy)
+    net->tensors[0].dev = const_cast<float*>(image_dev);
+    for (const auto& l : net->layers) {
+        const int rc = run_layer(*net, l, B, deltas_out, probs_out, st);
+        if (rc) return rc;
+    }
+    net->last_batch = B;
+    return SSD_OK;
+}
+
+int ssd_net_forward(ssd_net* net, const float* image_dev, int B, float* deltas_out_dev, float* probs_out_dev,
+                    void* stream) {
+    return forward_impl(net, image_dev, B, deltas_out_dev, probs_out_dev, (hipStream_t)stream);
+}
+
+int ssd_net_predict(ssd_net* net, const float* image_dev, int B, const float* priors_dev, const float* var,
+                    int max_total, float iou_thr, float score_thr, float* boxes_dev, float* labels_dev,
+                    float* scores_dev, int* valid_dev, void* stream) {
+    SSD_CHECK_ARG(net != nullptr, "ssd_net_predict: net is NULL");
+    if (!net->finalized) {
+        set_error("ssd_net_predict: call ssd_net_finalize() first");
+        return SSD_E_STATE;
+    }
+    const int N = net->num_priors, L = net->L;
+    if (!net->deltas) {
+        SSD_HIP(hipMalloc((void**)&net->deltas, (size_t)net->max_batch * N * 4 * sizeof(float)));
+        SSD_HIP(hipMalloc((void**)&net->probs, (size_t)net->max_batch * N * L * sizeof(float)));
+    }
+    const size_t need = ssd_decode_nms_workspace_bytes(net->max_batch, N, L, max_total);
+    if (need > net->nms_ws_bytes) {
+        if (net->nms_ws) (void)hipFree(net->nms_ws);
+        net->nms_ws = nullptr;
+        SSD_HIP(hipMalloc(&net->nms_ws, need));
+        net->nms_ws_bytes = need;
+    }
+    int rc = forward_impl(net, image_dev, B, net->deltas, net->probs, (hipStream_t)stream);
+    if (rc) return rc;
+    return ssd_decode_nms(net->deltas, net->probs, priors_dev, var, B, N, L, max_total, max_total, iou_thr,
+                          score_thr, boxes_dev, labels_dev, scores_dev, valid_dev, nullptr, net->nms_ws,
+                          net->nms_ws_bytes, stream);
+}
+
+long ssd_net_fetch_activation(ssd_net* net, const char* layer, float* host_out, size_t cap) {
+    if (!net || !layer) return SSD_E_INVALID;
+    auto it = net->tensor_index.find(layer);
+    if (it == net->tensor_index.end()) {
+        set_error("ssd_net_fetch_activation: unknown tensor '%s'", layer);
+        return SSD_E_INVALID;
+    }
+    const Tensor& t = net->tensors[it->second];
+    const size_t n = t.per_image * (size_t)net->last_batch;
+    if (!host_out) return (long)n;
+    if (cap < n) {
+        set_error("ssd_net_fetch_activation: buffer holds %zu floats, need %zu", cap, n);
+        return SSD_E_INVALID;
+    }
+    if (hipDeviceSynchronize() != hipSuccess || hipMemcpy(host_out, t.dev, n * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess) {
+        set_error("ssd_net_fetch_activation: copy failed");
+        return SSD_E_HIP;
+    }
+    return (long)n;
+}
+
+int ssd_net_num_layers(const ssd_net* net) { return net ? (int)net->layers.size() : 0; }
+const char* ssd_net_layer_name(const ssd_net* net, int i) {
+    return (net && i >= 0 && i < (int)net->layers.size()) ? net->layers[i].name.c_str() : "";
+}
+const char* ssd_net_layer_kind(const ssd_net* net, int i) {
+    return (net && i >= 0 && i < (int)net->layers.size()) ? kKindName[net->layers[i].kind] : "";
+}
+const char* ssd_net_layer_config(const ssd_net* net, int i) {
+    if (!net || i < 0 || i >= (int)net->layers.size() || net->layers[i].kind != LK_CONV) return "";
+    return conv_config_name(net->layers[i].cfg);
+}
+double ssd_net_layer_flops(const ssd_net* net, int i, int B) {
+    if (!net || i < 0 || i >= (int)net->layers.size()) return 0;
+    const Layer& l = net->layers[i];
+    const double px = (double)B * l.Ho * l.Wo;
+    if (l.kind == LK_CONV) return 2.0 * px * l.kh * l.kw * l.Cin * l.Cout;
+    if (l.kind == LK_DW) return 2.0 * px * 9 * l.Cout;
+    return 0;
+}
+double ssd_net_layer_bytes(const ssd_net* net, int i, int B) {
+    if (!net || i < 0 || i >= (int)net->layers.size()) return 0;
+    const Layer& l = net->layers[i];
+    if (l.kind == LK_SOFTMAX) return 2.0 * 4.0 * B * net->num_priors * net->L;
+    double b = 4.0 * B * ((double)l.H * l.W * l.Cin + (double)l.Ho * l.Wo * l.Cout);
+    if (l.res >= 0) b += 4.0 * B * (double)l.Ho * l.Wo * l.Cout;
+    if (l.kind == LK_CONV) b += 4.0 * l.kh * l.kw * l.Cin * l.Cout;
+    if (l.kind == LK_DW) b += 4.0 * 9 * l.Cout;
+    return b;
+}
+
+int ssd_net_profile_layers(ssd_net* net, const float* image_dev, int B, int reps, float* ms_out, void* stream) {
+    SSD_CHECK_ARG(net && image_dev && ms_out && reps >= 1, "ssd_net_profile_layers: bad arguments");
+    if (!net->finalized) {
+        set_error("ssd_net_profile_layers: call ssd_net_finalize() first");
+        return SSD_E_STATE;
+    }
+    SSD_CHECK_ARG(B >= 1 && B <= net->max_batch, "ssd_net_profile_layers: bad batch %d", B);
+    hipStream_t st = (hipStream_t)stream;
+    const int N = net->num_priors, L = net->L;
+    float *d = nullptr, *pr = nullptr;
+    SSD_HIP(hipMalloc((void**)&d, (size_t)B * N * 4 * sizeof(float)));
+    SSD_HIP(hipMalloc((void**)&pr, (size_t)B * N * L * sizeof(float)));
+    int rc = forward_impl(net, image_dev, B, d, pr, st);   // warm-up + valid inputs for each layer
+    hipEvent_t e0, e1;
+    (void)hipEventCreate(&e0);
+    (void)hipEventCreate(&e1);
+    for (size_t i = 0; i < net->layers.size() && !rc; ++i) {
+        (void)hipEventRecord(e0, st);
+        for (int r = 0; r < reps && !rc; ++r) rc = run_layer(*net, net->layers[i], B, d, pr, st);
+        (void)hipEventRecord(e1, st);
+        (void)hipEventSynchronize(e1);
+        float ms = 0.f;
+        (void)hipEventElapsedTime(&ms, e0, e1);
+        ms_out[i] = ms / reps;
+    }
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    (void)hipFree(d);
+    (void)hipFree(pr);
+    return rc;
+}
+
+}  // extern "C"

@@ -1,0 +1,189 @@
+"""Shared model object behind ``get_model`` of both backbones: a thin Python handle on the
+native graph runner (``ssd_net_*`` in include/ssd_hip.h).  PyTorch is the device-memory /
+stream provider only; weights live in the native net, keyed by the Keras variable names
+(``<layer>/<variable>``) in Keras layouts."""
+import ctypes
+
+import numpy as np
+import torch
+
+import ssd_hip as _h
+
+
+class SSDModel(object):
+    """Callable like the Keras model the reference builds: ``model(images) ->
+    (pred_deltas [B,N,4], pred_labels [B,N,L])``; also ``predict``, ``load_weights``,
+    ``save_weights``, ``get_weights``, ``set_weights``."""
+
+    def __init__(self, backbone, hyper_params, max_batch=None):
+        self.backbone = backbone
+        self.hyper_params = hyper_params
+        self.img_size = int(hyper_params["img_size"])
+        self.total_labels = int(hyper_params["total_labels"])
+        n_ars = [len(a) for a in hyper_params["aspect_ratios"]]
+        arr = (ctypes.c_int * len(n_ars))(*n_ars)
+        lib = _h.lib()
+        self._net = lib.ssd_net_create(_h.MOBILENET_V2 if backbone == "mobilenet_v2" else _h.VGG16,
+                                       self.img_size, len(n_ars), arr, self.total_labels)
+        if not self._net:
+            raise ValueError("ssd_net_create: %s" % lib.ssd_last_error().decode())
+        self.param_specs = []
+        for i in range(lib.ssd_net_num_params(self._net)):
+            name = lib.ssd_net_param_name(self._net, i).decode()
+            rank = lib.ssd_net_param_rank(self._net, i)
+            shp = lib.ssd_net_param_shape(self._net, i)
+            self.param_specs.append((name, tuple(shp[j] for j in range(rank))))
+        self.num_priors = lib.ssd_net_num_priors(self._net)
+        fm = [lib.ssd_net_feature_map_size(self._net, l) for l in range(len(n_ars))]
+        if list(fm) != [int(f) for f in hyper_params["feature_map_shapes"]]:
+            raise ValueError("feature_map_shapes %s do not match the %s graph at img_size %d (%s)" % (
+                hyper_params["feature_map_shapes"], backbone, self.img_size, fm))
+        self._max_batch = max_batch
+        self._finalized_for = 0
+        self._weights_set = False
+
+    def __del__(self):
+        try:
+            if getattr(self, "_net", None):
+                _h.lib().ssd_net_destroy(self._net)
+                self._net = None
+        except Exception:
+            pass
+
+    # ------------------------------------------------------------------ weights
+    def set_weights(self, weights):
+        """weights: dict name -> array in the Keras layout (missing names keep their value)."""
+        lib = _h.lib()
+        _h.device()
+        shapes = dict(self.param_specs)
+        for name, value in weights.items():
+            if name not in shapes:
+                raise ValueError("unknown parameter %r" % name)
+            a = np.ascontiguousarray(np.asarray(value, dtype=np.float32))
+            if tuple(a.shape) != shapes[name]:
+                raise ValueError("parameter %r has shape %s, expected %s" % (name, a.shape, shapes[name]))
+            _h.check(lib.ssd_net_set_param(self._net, name.encode(), a.ctypes.data_as(_h.c_float_p), a.size),
+                     "set_weights")
+        self._weights_set = True
+        self._finalized_for = 0
+
+    def get_weights(self):
+        lib = _h.lib()
+        out = {}
+        for name, shape in self.param_specs:
+            a = np.empty(shape, np.float32)
+            _h.check(lib.ssd_net_get_param(self._net, name.encode(), a.ctypes.data_as(_h.c_float_p), a.size),
+                     "get_weights")
+            out[name] = a
+        return out
+
+    def save_weights(self, path):
+        """Weights container: NumPy .npz keyed by Keras variable names (the reference's
+        HDF5 needs h5py, which is not available; utils/io_utils.py:17-29)."""
+        with open(path, "wb") as f:
+            np.savez(f, **self.get_weights())
+
+    def load_weights(self, path):
+        with np.load(path) as z:
+            self.set_weights({k: z[k] for k in z.files})
+
+    # ------------------------------------------------------------------ execution
+    def _ensure(self, B):
+        if not self._weights_set:
+            raise RuntimeError("model has no weights: call set_weights()/load_weights() first")
+        want = max(B, self._max_batch or 0)
+        if self._finalized_for < want:
+            _h.check(_h.lib().ssd_net_finalize(self._net, want), "ssd_net_finalize")
+            self._finalized_for = want
+
+    def __call__(self, images):
+        x = _h.to_dev(images)
+        if x.dim() != 4 or x.shape[1] != self.img_size or x.shape[2] != self.img_size or x.shape[3] != 3:
+            raise ValueError("expected images [B,%d,%d,3], got %s" % (self.img_size, self.img_size, tuple(x.shape)))
+        B = x.shape[0]
+        self._ensure(max(B, 1))
+        dev = x.device
+        deltas = torch.empty((B, self.num_priors, 4), dtype=torch.float32, device=dev)
+        probs = torch.empty((B, self.num_priors, self.total_labels), dtype=torch.float32, device=dev)
+        _h.check(_h.lib().ssd_net_forward(self._net, _h.ptr(x), B, _h.ptr(deltas), _h.ptr(probs), _h.stream()),
+                 "ssd_net_forward")
+        self._last_input = x   # keep the aliased input alive until the next call
+        return deltas, probs
+
+    def predict(self, x, batch_size=32, steps=None, verbose=0):
+        outs = ([], [])
+        n = x.shape[0]
+        for i in range(0, n, batch_size):
+            d, p = self(x[i:i + batch_size])
+            outs[0].append(d.cpu().numpy())
+            outs[1].append(p.cpu().numpy())
+        return np.concatenate(outs[0], 0), np.concatenate(outs[1], 0)
+
+    def fetch_activation(self, name):
+        """Activation of a named layer of the last forward (debug / parity tests)."""
+        lib = _h.lib()
+        n = lib.ssd_net_fetch_activation(self._net, name.encode(), None, 0)
+        if n < 0:
+            raise ValueError(lib.ssd_last_error().decode())
+        a = np.empty((n,), np.float32)
+        got = lib.ssd_net_fetch_activation(self._net, name.encode(), a.ctypes.data_as(_h.c_float_p), a.size)
+        if got < 0:
+            raise RuntimeError(lib.ssd_last_error().decode())
+        return a
+
+    def layers(self, B):
+        lib = _h.lib()
+        out = []
+        for i in range(lib.ssd_net_num_layers(self._net)):
+            out.append({"name": lib.ssd_net_layer_name(self._net, i).decode(),
+                        "kind": lib.ssd_net_layer_kind(self._net, i).decode(),
+                        "config": lib.ssd_net_layer_config(self._net, i).decode(),
+                        "flops": lib.ssd_net_layer_flops(self._net, i, B),
+                        "bytes": lib.ssd_net_layer_bytes(self._net, i, B)})
+        return out
+
+    def profile_layers(self, images, reps=5):
+        x = _h.to_dev(images)
+        B = x.shape[0]
+        self._ensure(B)
+        n = _h.lib().ssd_net_num_layers(self._net)
+        ms = (ctypes.c_float * n)()
+        _h.check(_h.lib().ssd_net_profile_layers(self._net, _h.ptr(x), B, reps, ms, _h.stream()), "profile_layers")
+        info = self.layers(B)
+        for i, rec in enumerate(info):
+            rec["ms"] = float(ms[i])
+        return info
+
+
+def keras_default_init(param_specs, backbone, seed=0):
+    """Host-side initial weights: what ``get_model`` leaves in a freshly built Keras model.
+    Conv kernels: glorot_uniform (Keras default; extras + heads, models/header.py:60-61) or
+    glorot_normal (VGG16, models/ssd_vgg16.py:44); biases 0; BatchNorm gamma 1, beta 0,
+    mean 0, variance 1; L2Normalization scale 20.  The MobileNetV2 backbone would load
+    ImageNet weights (models/ssd_mobilenet_v2.py:16) -- no network here, so it gets He-normal
+    kernels instead."""
+    rng = np.random.default_rng(seed)
+    w = {}
+    for name, shape in param_specs:
+        var = name.rsplit("/", 1)[1]
+        if var in ("kernel", "depthwise_kernel"):
+            kh, kw, cin, cout = shape
+            fan_in, fan_out = kh * kw * cin, kh * kw * cout
+            if var == "depthwise_kernel":
+                fan_in, fan_out = kh * kw, kh * kw
+            is_backbone = backbone == "mobilenet_v2" and not (name.startswith("extra") or name[0].isdigit())
+            if is_backbone:
+                a = rng.standard_normal(shape) * np.sqrt(2.0 / fan_in)
+            elif backbone == "vgg16" and not name[0].isdigit():
+                a = rng.standard_normal(shape) * np.sqrt(2.0 / (fan_in + fan_out))
+            else:
+                lim = np.sqrt(6.0 / (fan_in + fan_out))
+                a = rng.uniform(-lim, lim, shape)
+            w[name] = a.astype(np.float32)
+        elif var in ("gamma", "moving_variance"):
+            w[name] = np.ones(shape, np.float32)
+        elif var == "scale":
+            w[name] = np.full(shape, 20.0, np.float32)
+        else:
+            w[name] = np.zeros(shape, np.float32)
+    return w

@@ -52,6 +52,10 @@ _SIGNATURES = {
     "ssd_conv_pack_weights": (ctypes.c_int, [vp] + [ctypes.c_int] * 4 + [vp, vp]),
     "ssd_conv2d": (ctypes.c_int, [ctypes.POINTER(ConvDesc), vp, vp, vp, vp, vp, vp,
                                   ctypes.c_long, ctypes.c_long, vp]),
+    "ssd_conv_num_configs": (ctypes.c_int, []),
+    "ssd_conv_config_name": (ctypes.c_char_p, [ctypes.c_int]),
+    "ssd_conv2d_ex": (ctypes.c_int, [ctypes.POINTER(ConvDesc), vp, vp, vp, vp, vp, vp,
+                                     ctypes.c_long, ctypes.c_long, ctypes.c_int, ctypes.c_int, vp, vp]),
     "ssd_dwconv3x3": (ctypes.c_int, [vp] + [ctypes.c_int] * 9 + [vp, vp, vp, ctypes.c_int, vp, vp]),
     "ssd_maxpool2d": (ctypes.c_int, [vp] + [ctypes.c_int] * 10 + [vp, vp]),
     "ssd_l2norm": (ctypes.c_int, [vp, ctypes.c_long, ctypes.c_int, vp, vp, vp]),
@@ -74,6 +78,7 @@ _SIGNATURES = {
     "ssd_net_num_layers": (ctypes.c_int, [vp]),
     "ssd_net_layer_name": (ctypes.c_char_p, [vp, ctypes.c_int]),
     "ssd_net_layer_kind": (ctypes.c_char_p, [vp, ctypes.c_int]),
+    "ssd_net_layer_config": (ctypes.c_char_p, [vp, ctypes.c_int]),
     "ssd_net_layer_flops": (ctypes.c_double, [vp, ctypes.c_int, ctypes.c_int]),
     "ssd_net_layer_bytes": (ctypes.c_double, [vp, ctypes.c_int, ctypes.c_int]),
     "ssd_net_profile_layers": (ctypes.c_int, [vp, vp, ctypes.c_int, ctypes.c_int, c_float_p, vp]),
