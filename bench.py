@@ -1,0 +1,180 @@
+#!/usr/bin/env python
+"""Headline benchmark: images/sec of the SSD300 forward + decode/NMS hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+One "step" = one pass of the hot path over one synthetic batch already resident in HBM:
+``get_decoder_model(ssd_model, priors, hp)`` applied to ``[B,300,300,3]`` fp32 images
+(BASELINE.json configs[1]: SSD300 MobileNetV2, batch 64, fp32, fwd + decode/NMS).  Images
+shard by batch (one process per GPU, weights + priors replicated, NO data-path collective:
+inference is embarrassingly parallel); scaling is weak (B per GPU fixed).
+
+Rank 0 prints ONE JSON line with the whole-job images/sec, the roofline of the dominant
+kernel family (fp32 MFMA implicit-GEMM conv, measured live with hipEvents on the launch
+stream) and, at N=1, the CPU baseline (torch-CPU/oneDNN port of the same graph + the plain-C
+decode/NMS oracle on the host cores; the literal TF-CPU path cannot run here).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+for _p in (REPO, os.path.join(REPO, "tf-ssd_amd")):
+    if _p not in sys.path:
+        sys.path.insert(0, _p)
+
+PEAK_FP32_MFMA_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md (v_mfma_f32_16x16x4_f32)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=None, help="images per GPU per step (default 64 / 32 for vgg16)")
+    ap.add_argument("--backbone", default="mobilenet_v2", choices=["mobilenet_v2", "vgg16"])
+    ap.add_argument("--cpu-sample", type=int, default=8, help="images per pass of the CPU baseline")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--layers", action="store_true", help="also print the per-layer table to stderr")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and world > 1:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    import ssd_hip
+    from utils import bbox_utils, train_utils, data_utils
+    from models.decoder import get_decoder_model
+    if args.backbone == "mobilenet_v2":
+        from models.ssd_mobilenet_v2 import get_model
+    else:
+        from models.ssd_vgg16 import get_model
+
+    B = args.batch or (64 if args.backbone == "mobilenet_v2" else 32)
+    hp = dict(train_utils.get_hyper_params(args.backbone))
+    hp["total_labels"] = 21                      # "bg" + 20 VOC classes (predictor.py:25-27)
+    model = get_model(hp, max_batch=B)
+    weights = data_utils.synthetic_weights(model, seed=1)
+    priors = bbox_utils.generate_prior_boxes(hp["feature_map_shapes"], hp["aspect_ratios"])
+    decoder_model = get_decoder_model(model, priors, hp)
+    x = ssd_hip.to_dev(data_utils.synthetic_images(B, hp["img_size"], seed=rank))   # resident in HBM
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+
+    for _ in range(max(args.warmup, 1)):
+        out = decoder_model(x)
+    torch.cuda.synchronize()
+    barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = decoder_model(x)
+    torch.cuda.synchronize()
+    barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    valid = decoder_model.decoder.last_valid_detections
+    mean_det = float(valid.float().mean().item())
+
+    # ---- roofline leg: same K steps with per-layer hipEvents on the launch stream
+    model.set_timing(True)
+    for _ in range(args.steps):
+        decoder_model(x)
+    info, nfw = model.read_timing(B)
+    model.set_timing(False)
+    mfma = [r for r in info if r["kind"] == "conv" and r["config"].startswith("mfma_")]
+    mfma_ms = sum(r["ms"] for r in mfma)
+    mfma_flops = sum(r["flops"] for r in mfma)
+    total_ms = sum(r["ms"] for r in info)
+    kinds = {}
+    for r in info:
+        k = r["kind"] if not (r["kind"] == "conv" and not r["config"].startswith("mfma_")) else "conv_direct"
+        kinds[k] = kinds.get(k, 0.0) + r["ms"]
+    achieved = mfma_flops / (mfma_ms * 1e-3) / 1e12 if mfma_ms > 0 else 0.0
+    if args.layers and rank == 0:
+        for r in info:
+            sys.stderr.write("%-28s %-8s %-22s %8.4f ms %8.2f GFLOP %7.1f MB  %6.1f TF/s %6.0f GB/s\n" % (
+                r["name"], r["kind"], r["config"], r["ms"], r["flops"] / 1e9, r["bytes"] / 1e6,
+                r["flops"] / max(r["ms"], 1e-9) / 1e9, r["bytes"] / max(r["ms"], 1e-9) / 1e6))
+
+    result = {
+        "metric": "images/sec SSD300 (%s) fwd+NMS" % ("MobileNetV2" if args.backbone == "mobilenet_v2" else "VGG16"),
+        "value": world * B * args.steps / elapsed,
+        "unit": "images/sec",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": 1e3 * elapsed / args.steps,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f32",
+        "data": "synthetic (seeded uniform [0,1) images, seeded random weights; no dataset/checkpoint offline)",
+        "config": {"workload": "SSD300 %s inference, batch=%d per GPU, 300x300 fp32, fwd + decode/NMS (BASELINE.json configs[%d])" % (
+                       args.backbone, B, 1 if args.backbone == "mobilenet_v2" else 2),
+                   "global_batch": world * B, "priors": model.num_priors, "labels": hp["total_labels"],
+                   "mean_detections_per_image": mean_det, "parallelism": "batch-sharded x%d, no collective" % world},
+        "roofline": {"bound": "mfma", "kernel": "conv_mfma_kernel (fp32 v_mfma_f32_16x16x4 implicit-GEMM conv, all tile configs)",
+                     "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                     "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": None,
+                     "launches_per_step": len(mfma), "kernel_ms_per_step": mfma_ms,
+                     "algorithmic_gflop_per_step": mfma_flops / 1e9},
+        "gpu_ms_per_step_by_kind": {k: round(v, 4) for k, v in sorted(kinds.items())},
+        "gpu_ms_per_step_sum": total_ms,
+    }
+
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        result["cpu_baseline"] = cpu_baseline(args.backbone, hp, weights, priors.cpu().numpy(), args.cpu_sample)
+    if rank == 0:
+        print(json.dumps(result), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+def cpu_baseline(backbone, hp, weights, priors, sample):
+    """The oracle's port timed on the host cores: torch-CPU (oneDNN) convs of the identical
+    graph + the plain-C decode/NMS restatement, on a bounded sample of the same workload."""
+    import numpy as np
+    import torch
+    from oracle import torch_cpu_graph as tg
+    from oracle import c_oracle as co
+    from utils import data_utils
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    x = data_utils.synthetic_images(sample, hp["img_size"], seed=0)
+    tg.forward(backbone, hp, weights, x[:1])          # warm-up (oneDNN primitive creation)
+    t0 = time.perf_counter()
+    passes = 0
+    while True:
+        d, p = tg.forward(backbone, hp, weights, x)
+        co.decode_nms(d, p, priors, hp["variances"])
+        passes += 1
+        if time.perf_counter() - t0 > 10.0 or passes >= 20:
+            break
+    dt = time.perf_counter() - t0
+    return {"value": sample * passes / dt, "unit": "images/sec", "cores": cores, "kind": "port",
+            "sample": "%d passes of %d images (torch-CPU oneDNN graph with TF padding + C decode/NMS oracle; "
+                      "TensorFlow itself is not installable here)" % (passes, sample)}
+
+
+if __name__ == "__main__":
+    main()

@@ -218,6 +218,11 @@ const char* ssd_net_layer_kind(const ssd_net* net, int i);   /* "conv","dw","poo
 const char* ssd_net_layer_config(const ssd_net* net, int i); /* autotuned conv tile config */
 double ssd_net_layer_flops(const ssd_net* net, int i, int B); /* 2*MACs                  */
 double ssd_net_layer_bytes(const ssd_net* net, int i, int B); /* in + out + weights      */
+/* Live per-layer hipEvent timing of ssd_net_forward / ssd_net_predict on their stream.
+ * read_timing sums the durations (ms) of the forwards recorded since the last read into
+ * ms_sum_out[num_layers + 1] (last entry: decode+NMS of predict) and reports their count. */
+int ssd_net_set_timing(ssd_net* net, int enabled);
+int ssd_net_read_timing(ssd_net* net, float* ms_sum_out, int* forwards_out);
 /* Time every layer with hipEvents on `stream` (reps forwards); ms_out[num_layers]. */
 int ssd_net_profile_layers(ssd_net* net, const float* image_dev, int B, int reps,
                            float* ms_out, void* stream);

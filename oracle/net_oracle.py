@@ -150,6 +150,43 @@ def softmax(x):
     return (e / np.sum(e, -1, keepdims=True, dtype=F32)).astype(F32)
 
 
+class NumpyOps(object):
+    """Default op set of the graphs below (plain NumPy).  oracle/torch_cpu_graph.py provides
+    the same interface on torch-CPU (oneDNN) for the multi-threaded CPU baseline."""
+    conv2d = staticmethod(conv2d)
+    depthwise_conv2d = staticmethod(depthwise_conv2d)
+    batch_norm = staticmethod(batch_norm)
+    relu = staticmethod(relu)
+    relu6 = staticmethod(relu6)
+    max_pool = staticmethod(max_pool)
+    l2_normalize_scale = staticmethod(l2_normalize_scale)
+    softmax = staticmethod(softmax)
+
+    @staticmethod
+    def add(a, b):
+        return a + b
+
+    @staticmethod
+    def reshape(a, shape):
+        return a.reshape(shape)
+
+    @staticmethod
+    def concat(parts, axis):
+        return np.concatenate(parts, axis)
+
+    @staticmethod
+    def hw(x):
+        return x.shape[1], x.shape[2]
+
+    @staticmethod
+    def input(x):
+        return np.asarray(x, F32)
+
+    @staticmethod
+    def output(x):
+        return np.asarray(x, F32)
+
+
 # ------------------------------------------------------------------ graph specs
 # MobileNetV2 inverted-residual table (t, c, n, s) -> 16 blocks after expanded_conv.
 _MBV2_BLOCKS = [(24, 2), (24, 1), (32, 2), (32, 1), (32, 1), (64, 2), (64, 1), (64, 1), (64, 1),
@@ -227,96 +264,97 @@ def param_specs(backbone, hyper_params):
 
 
 # ------------------------------------------------------------------ forward graphs
-def heads_forward(hyper_params, feats, P, acts=None):
+def heads_forward(hyper_params, feats, P, acts=None, ops=NumpyOps):
     """models/header.py:43-67 + HeadWrapper (:34-41) + softmax (:64)."""
     L = hyper_params["total_labels"]
     labels, boxes = [], []
     for i, f in enumerate(feats, start=1):
         B = f.shape[0]
-        lab = conv2d(f, P["%d_conv_label_output/kernel" % i], P["%d_conv_label_output/bias" % i])
-        box = conv2d(f, P["%d_conv_boxes_output/kernel" % i], P["%d_conv_boxes_output/bias" % i])
-        labels.append(lab.reshape(B, -1, L))
-        boxes.append(box.reshape(B, -1, 4))
-    logits = np.concatenate(labels, 1)
+        lab = ops.conv2d(f, P["%d_conv_label_output/kernel" % i], P["%d_conv_label_output/bias" % i])
+        box = ops.conv2d(f, P["%d_conv_boxes_output/kernel" % i], P["%d_conv_boxes_output/bias" % i])
+        labels.append(ops.reshape(lab, (B, -1, L)))
+        boxes.append(ops.reshape(box, (B, -1, 4)))
+    logits = ops.concat(labels, 1)
     if acts is not None:
-        acts["labels_head"] = logits
-    return np.concatenate(boxes, 1).astype(F32), softmax(logits)
+        acts["labels_head"] = ops.output(logits)
+    return ops.output(ops.concat(boxes, 1)), ops.output(ops.softmax(logits))
 
 
-def mobilenet_v2_ssd_forward(hyper_params, P, x, acts=None):
+def mobilenet_v2_ssd_forward(hyper_params, P, x, acts=None, ops=NumpyOps):
     """models/ssd_mobilenet_v2.py:7-35 + [3P] MobileNetV2 (Appendix A).  x [B,S,S,3] in [0,1]."""
     def rec(name, v):
         if acts is not None:
-            acts[name] = v
+            acts[name] = ops.output(v)
         return v
 
     def bn(name, v):
-        return batch_norm(v, P[name + "/gamma"], P[name + "/beta"], P[name + "/moving_mean"], P[name + "/moving_variance"])
-    x = np.asarray(x, F32)
-    pt, pb = correct_pad(x.shape[1])
-    pl, pr = correct_pad(x.shape[2])
-    y = conv2d(x, P["Conv1/kernel"], stride=2, padding=(pt, pb, pl, pr))
-    y = rec("Conv1_relu", relu6(bn("bn_Conv1", y)))
-    y = depthwise_conv2d(y, P["expanded_conv_depthwise/depthwise_kernel"])
-    y = rec("expanded_conv_depthwise_relu", relu6(bn("expanded_conv_depthwise_BN", y)))
-    y = rec("expanded_conv_project_BN", bn("expanded_conv_project_BN", conv2d(y, P["expanded_conv_project/kernel"])))
+        return ops.batch_norm(v, P[name + "/gamma"], P[name + "/beta"], P[name + "/moving_mean"],
+                              P[name + "/moving_variance"])
+    x = ops.input(x)
+    pt, pb = correct_pad(ops.hw(x)[0])
+    pl, pr = correct_pad(ops.hw(x)[1])
+    y = ops.conv2d(x, P["Conv1/kernel"], stride=2, padding=(pt, pb, pl, pr))
+    y = rec("Conv1_relu", ops.relu6(bn("bn_Conv1", y)))
+    y = ops.depthwise_conv2d(y, P["expanded_conv_depthwise/depthwise_kernel"])
+    y = rec("expanded_conv_depthwise_relu", ops.relu6(bn("expanded_conv_depthwise_BN", y)))
+    y = rec("expanded_conv_project_BN", bn("expanded_conv_project_BN", ops.conv2d(y, P["expanded_conv_project/kernel"])))
     cin = 16
     tap1 = None
     for k, (cout, s) in enumerate(_MBV2_BLOCKS, start=1):
         p = "block_%d_" % k
         inp = y
-        y = rec(p + "expand_relu", relu6(bn(p + "expand_BN", conv2d(y, P[p + "expand/kernel"]))))
+        y = rec(p + "expand_relu", ops.relu6(bn(p + "expand_BN", ops.conv2d(y, P[p + "expand/kernel"]))))
         if k == 13:
             tap1 = y                                   # block_13_expand_relu (ssd_mobilenet_v2.py:18)
         if s == 2:
-            pt, pb = correct_pad(y.shape[1])
-            pl, pr = correct_pad(y.shape[2])
-            y = depthwise_conv2d(y, P[p + "depthwise/depthwise_kernel"], stride=2, padding=(pt, pb, pl, pr))
+            pt, pb = correct_pad(ops.hw(y)[0])
+            pl, pr = correct_pad(ops.hw(y)[1])
+            y = ops.depthwise_conv2d(y, P[p + "depthwise/depthwise_kernel"], stride=2, padding=(pt, pb, pl, pr))
         else:
-            y = depthwise_conv2d(y, P[p + "depthwise/depthwise_kernel"])
-        y = rec(p + "depthwise_relu", relu6(bn(p + "depthwise_BN", y)))
-        y = bn(p + "project_BN", conv2d(y, P[p + "project/kernel"]))
+            y = ops.depthwise_conv2d(y, P[p + "depthwise/depthwise_kernel"])
+        y = rec(p + "depthwise_relu", ops.relu6(bn(p + "depthwise_BN", y)))
+        y = bn(p + "project_BN", ops.conv2d(y, P[p + "project/kernel"]))
         if cin == cout and s == 1:
-            y = inp + y
+            y = ops.add(inp, y)
         y = rec(p + "out", y)
         cin = cout
-    y = rec("out_relu", relu6(bn("Conv_1_bn", conv2d(y, P["Conv_1/kernel"]))))
+    y = rec("out_relu", ops.relu6(bn("Conv_1_bn", ops.conv2d(y, P["Conv_1/kernel"]))))
     feats = [tap1, y]
     for i in range(1, 5):
-        y = rec("extra%d_1" % i, relu(conv2d(y, P["extra%d_1/kernel" % i], P["extra%d_1/bias" % i], padding="valid")))
-        y = rec("extra%d_2" % i, relu(conv2d(y, P["extra%d_2/kernel" % i], P["extra%d_2/bias" % i], stride=2, padding="same")))
+        y = rec("extra%d_1" % i, ops.relu(ops.conv2d(y, P["extra%d_1/kernel" % i], P["extra%d_1/bias" % i], padding="valid")))
+        y = rec("extra%d_2" % i, ops.relu(ops.conv2d(y, P["extra%d_2/kernel" % i], P["extra%d_2/bias" % i], stride=2, padding="same")))
         feats.append(y)
-    return heads_forward(hyper_params, feats, P, acts)
+    return heads_forward(hyper_params, feats, P, acts, ops)
 
 
-def vgg16_ssd_forward(hyper_params, P, x, acts=None):
+def vgg16_ssd_forward(hyper_params, P, x, acts=None, ops=NumpyOps):
     """models/ssd_vgg16.py:33-97."""
     def rec(name, v):
         if acts is not None:
-            acts[name] = v
+            acts[name] = ops.output(v)
         return v
 
     def c(name, v, **kw):
-        return rec(name, relu(conv2d(v, P[name + "/kernel"], P[name + "/bias"], **kw)))
-    y = np.asarray(x, F32)
-    y = c("conv1_2", c("conv1_1", y)); y = rec("pool1", max_pool(y, 2, 2))
-    y = c("conv2_2", c("conv2_1", y)); y = rec("pool2", max_pool(y, 2, 2))
-    y = c("conv3_3", c("conv3_2", c("conv3_1", y))); y = rec("pool3", max_pool(y, 2, 2))
-    conv4_3 = c("conv4_3", c("conv4_2", c("conv4_1", y))); y = rec("pool4", max_pool(conv4_3, 2, 2))
-    y = c("conv5_3", c("conv5_2", c("conv5_1", y))); y = rec("pool5", max_pool(y, 3, 1))
+        return rec(name, ops.relu(ops.conv2d(v, P[name + "/kernel"], P[name + "/bias"], **kw)))
+    y = ops.input(x)
+    y = c("conv1_2", c("conv1_1", y)); y = rec("pool1", ops.max_pool(y, 2, 2))
+    y = c("conv2_2", c("conv2_1", y)); y = rec("pool2", ops.max_pool(y, 2, 2))
+    y = c("conv3_3", c("conv3_2", c("conv3_1", y))); y = rec("pool3", ops.max_pool(y, 2, 2))
+    conv4_3 = c("conv4_3", c("conv4_2", c("conv4_1", y))); y = rec("pool4", ops.max_pool(conv4_3, 2, 2))
+    y = c("conv5_3", c("conv5_2", c("conv5_1", y))); y = rec("pool5", ops.max_pool(y, 3, 1))
     y = c("conv6", y, dilation=6)
     conv7 = c("conv7", y)
     conv8_2 = c("conv8_2", c("conv8_1", conv7, padding="valid"), stride=2, padding="same")
     conv9_2 = c("conv9_2", c("conv9_1", conv8_2, padding="valid"), stride=2, padding="same")
     conv10_2 = c("conv10_2", c("conv10_1", conv9_2, padding="valid"), padding="valid")
     conv11_2 = c("conv11_2", c("conv11_1", conv10_2, padding="valid"), padding="valid")
-    norm = rec("l2_normalization", l2_normalize_scale(conv4_3, P["l2_normalization/scale"]))
-    return heads_forward(hyper_params, [norm, conv7, conv8_2, conv9_2, conv10_2, conv11_2], P, acts)
+    norm = rec("l2_normalization", ops.l2_normalize_scale(conv4_3, P["l2_normalization/scale"]))
+    return heads_forward(hyper_params, [norm, conv7, conv8_2, conv9_2, conv10_2, conv11_2], P, acts, ops)
 
 
-def forward(backbone, hyper_params, P, x, acts=None):
+def forward(backbone, hyper_params, P, x, acts=None, ops=NumpyOps):
     fn = mobilenet_v2_ssd_forward if backbone == "mobilenet_v2" else vgg16_ssd_forward
-    return fn(hyper_params, P, x, acts)
+    return fn(hyper_params, P, x, acts, ops)
 
 
 def count_macs(backbone, hyper_params, S=300):
@@ -326,21 +364,18 @@ def count_macs(backbone, hyper_params, S=300):
         if n.endswith("moving_variance"):
             P[n] += 1
     macs = {"total": 0}
-    global conv2d, depthwise_conv2d
-    oc, od = conv2d, depthwise_conv2d
 
-    def c2(x, w, *a, **k):
-        out = oc(x, w, *a, **k)
-        macs["total"] += out.shape[1] * out.shape[2] * w.shape[0] * w.shape[1] * w.shape[2] * w.shape[3]
-        return out
+    class Counting(NumpyOps):
+        @staticmethod
+        def conv2d(x, w, *a, **k):
+            out = conv2d(x, w, *a, **k)
+            macs["total"] += out.shape[1] * out.shape[2] * int(np.prod(w.shape))
+            return out
 
-    def d2(x, w, *a, **k):
-        out = od(x, w, *a, **k)
-        macs["total"] += out.shape[1] * out.shape[2] * 9 * out.shape[3]
-        return out
-    conv2d, depthwise_conv2d = c2, d2
-    try:
-        forward(backbone, hyper_params, P, np.zeros((1, S, S, 3), F32))
-    finally:
-        conv2d, depthwise_conv2d = oc, od
+        @staticmethod
+        def depthwise_conv2d(x, w, *a, **k):
+            out = depthwise_conv2d(x, w, *a, **k)
+            macs["total"] += out.shape[1] * out.shape[2] * 9 * out.shape[3]
+            return out
+    forward(backbone, hyper_params, P, np.zeros((1, S, S, 3), F32), ops=Counting)
     return macs["total"]

@@ -79,6 +79,9 @@ struct ssd_net {
     float* probs = nullptr;
     void* nms_ws = nullptr;
     size_t nms_ws_bytes = 0;
+    // optional per-layer hipEvent timing of forward()/predict() (bench.py roofline leg)
+    bool timing = false;
+    std::vector<std::vector<hipEvent_t>> timing_events;   // one vector of (layers + 2) events per forward
 
     ~ssd_net() {
         for (auto& p : params)
@@ -90,6 +93,8 @@ struct ssd_net {
         if (deltas) (void)hipFree(deltas);
         if (probs) (void)hipFree(probs);
         if (nms_ws) (void)hipFree(nms_ws);
+        for (auto& v : timing_events)
+            for (auto e : v) (void)hipEventDestroy(e);
     }
 };
 
@@ -556,9 +561,17 @@ static int forward_impl(ssd_net* net, const float* image_dev, int B, float* delt
                   "ssd_net_forward: outputs must be 16-byte aligned");
     // the input tensor aliases the caller's image buffer (no copy)
     net->tensors[0].dev = const_cast<float*>(image_dev);
-    for (const auto& l : net->layers) {
-        const int rc = run_layer(*net, l, B, deltas_out, probs_out, st);
+    std::vector<hipEvent_t>* ev = nullptr;
+    if (net->timing) {
+        net->timing_events.emplace_back(net->layers.size() + 2);
+        ev = &net->timing_events.back();
+        for (auto& e : *ev) SSD_HIP(hipEventCreate(&e));
+        (void)hipEventRecord((*ev)[0], st);
+    }
+    for (size_t i = 0; i < net->layers.size(); ++i) {
+        const int rc = run_layer(*net, net->layers[i], B, deltas_out, probs_out, st);
         if (rc) return rc;
+        if (ev) (void)hipEventRecord((*ev)[i + 1], st);
     }
     net->last_batch = B;
     return SSD_OK;
@@ -591,9 +604,40 @@ int ssd_net_predict(ssd_net* net, const float* image_dev, int B, const float* pr
     }
     int rc = forward_impl(net, image_dev, B, net->deltas, net->probs, (hipStream_t)stream);
     if (rc) return rc;
-    return ssd_decode_nms(net->deltas, net->probs, priors_dev, var, B, N, L, max_total, max_total, iou_thr,
-                          score_thr, boxes_dev, labels_dev, scores_dev, valid_dev, nullptr, net->nms_ws,
-                          net->nms_ws_bytes, stream);
+    rc = ssd_decode_nms(net->deltas, net->probs, priors_dev, var, B, N, L, max_total, max_total, iou_thr,
+                        score_thr, boxes_dev, labels_dev, scores_dev, valid_dev, nullptr, net->nms_ws,
+                        net->nms_ws_bytes, stream);
+    if (!rc && net->timing && !net->timing_events.empty())
+        (void)hipEventRecord(net->timing_events.back().back(), (hipStream_t)stream);
+    return rc;
+}
+
+int ssd_net_set_timing(ssd_net* net, int enabled) {
+    SSD_CHECK_ARG(net != nullptr, "ssd_net_set_timing: net is NULL");
+    net->timing = enabled != 0;
+    return SSD_OK;
+}
+
+// Sum of per-layer durations (ms) over the forwards recorded since the last read;
+// ms_sum_out has num_layers + 1 entries, the last one being decode+NMS (predict only).
+int ssd_net_read_timing(ssd_net* net, float* ms_sum_out, int* forwards_out) {
+    SSD_CHECK_ARG(net && ms_sum_out && forwards_out, "ssd_net_read_timing: NULL argument");
+    const size_t nl = net->layers.size();
+    for (size_t i = 0; i <= nl; ++i) ms_sum_out[i] = 0.f;
+    SSD_HIP(hipDeviceSynchronize());
+    for (auto& ev : net->timing_events) {
+        for (size_t i = 0; i < nl; ++i) {
+            float ms = 0.f;
+            if (hipEventElapsedTime(&ms, ev[i], ev[i + 1]) == hipSuccess) ms_sum_out[i] += ms;
+        }
+        float ms = 0.f;
+        if (hipEventQuery(ev[nl + 1]) == hipSuccess && hipEventElapsedTime(&ms, ev[nl], ev[nl + 1]) == hipSuccess)
+            ms_sum_out[nl] += ms;
+        for (auto e : ev) (void)hipEventDestroy(e);
+    }
+    *forwards_out = (int)net->timing_events.size();
+    net->timing_events.clear();
+    return SSD_OK;
 }
 
 long ssd_net_fetch_activation(ssd_net* net, const char* layer, float* host_out, size_t cap) {

@@ -142,6 +142,45 @@ class SSDModel(object):
                         "bytes": lib.ssd_net_layer_bytes(self._net, i, B)})
         return out
 
+    def predict_on_device(self, images, priors, variances, max_total=200, iou_threshold=0.5,
+                          score_threshold=0.5):
+        """Forward + SSDDecoder in ONE native call (``ssd_net_predict``): what
+        ``get_decoder_model(...).predict`` runs per batch.  Returns device tensors
+        (boxes, labels, scores, valid)."""
+        x = _h.to_dev(images)
+        B = x.shape[0]
+        self._ensure(max(B, 1))
+        pri = _h.to_dev(priors)
+        dev = x.device
+        boxes = torch.empty((B, max_total, 4), dtype=torch.float32, device=dev)
+        labels = torch.empty((B, max_total), dtype=torch.float32, device=dev)
+        scores = torch.empty((B, max_total), dtype=torch.float32, device=dev)
+        valid = torch.empty((B,), dtype=torch.int32, device=dev)
+        var_p, _keep = _h.host4(variances)
+        _h.check(_h.lib().ssd_net_predict(self._net, _h.ptr(x), B, _h.ptr(pri), var_p, int(max_total),
+                                          float(iou_threshold), float(score_threshold), _h.ptr(boxes),
+                                          _h.ptr(labels), _h.ptr(scores), _h.ptr(valid), _h.stream()),
+                 "ssd_net_predict")
+        self._last_input = x
+        return boxes, labels, scores, valid
+
+    def set_timing(self, enabled):
+        _h.check(_h.lib().ssd_net_set_timing(self._net, int(enabled)), "set_timing")
+
+    def read_timing(self, B):
+        """Per-layer mean ms over the forwards since the last read (+ 'decode_nms' row)."""
+        lib = _h.lib()
+        n = lib.ssd_net_num_layers(self._net)
+        ms = (ctypes.c_float * (n + 1))()
+        cnt = ctypes.c_int(0)
+        _h.check(lib.ssd_net_read_timing(self._net, ms, ctypes.byref(cnt)), "read_timing")
+        info = self.layers(B)
+        info.append({"name": "decode_nms", "kind": "nms", "config": "", "flops": 0.0, "bytes": 0.0})
+        k = max(cnt.value, 1)
+        for i, rec in enumerate(info):
+            rec["ms"] = float(ms[i]) / k
+        return info, cnt.value
+
     def profile_layers(self, images, reps=5):
         x = _h.to_dev(images)
         B = x.shape[0]

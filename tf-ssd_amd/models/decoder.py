@@ -80,8 +80,15 @@ class DecoderModel(object):
         self.decoder = decoder
 
     def __call__(self, images):
+        d = self.decoder
+        if hasattr(self.base_model, "predict_on_device"):
+            b, l, s, v = self.base_model.predict_on_device(
+                images, d.prior_boxes, d.variances, max_total=d.max_total_size,
+                iou_threshold=d.iou_threshold, score_threshold=d.score_threshold)
+            d.last_valid_detections = v
+            return b, l, s
         deltas, probs = self.base_model(images)
-        return self.decoder([deltas, probs])
+        return d([deltas, probs])
 
     def predict_on_batch(self, images):
         return tuple(t.cpu().numpy() for t in self(images))

@@ -1,0 +1,106 @@
+"""Data side of the drop-in.  The reference's ``utils/data_utils.py`` loads PASCAL VOC via
+tensorflow_datasets and resizes on the host; that input pipeline is OUT OF SCOPE of this
+build (needs tfds + network; the metric uses synthetic batches).  What is
+kept: the VOC label list, the padded-batch conventions (gt boxes padded with 0, labels with
+-1), and seeded synthetic generators shaped like the reference's batches."""
+import numpy as np
+
+VOC_LABELS = ["aeroplane", "bicycle", "bird", "boat", "bottle", "bus", "car", "cat", "chair", "cow",
+              "diningtable", "dog", "horse", "motorbike", "person", "pottedplant", "sheep", "sofa",
+              "train", "tvmonitor"]
+
+
+def get_labels(info=None):
+    """reference utils/data_utils.py:70-78 (``info.features["labels"].names`` for VOC)."""
+    return list(VOC_LABELS)
+
+
+def get_dataset(name, split, data_dir="~/tensorflow_datasets"):
+    """reference utils/data_utils.py:32-45 -- tfds is not available in this build."""
+    assert split in ["train", "train+validation", "validation", "test"]
+    raise RuntimeError("tensorflow_datasets is not available; use synthetic_dataset() or feed arrays "
+                       "[B,S,S,3] float32 in [0,1] directly")
+
+
+def get_padding_values():
+    """reference utils/data_utils.py:117-122: image 0, gt boxes 0, gt labels -1."""
+    return (np.float32(0), np.float32(0), np.int32(-1))
+
+
+def synthetic_images(batch, img_size=300, seed=0):
+    """uint8->float32 [0,1] images like ``preprocessing`` yields (utils/data_utils.py:22)."""
+    return np.random.default_rng(seed).random((batch, img_size, img_size, 3), dtype=np.float32)
+
+
+def synthetic_gt(batch, max_boxes=16, total_labels=21, seed=3):
+    rng = np.random.default_rng(seed)
+    gt = np.zeros((batch, max_boxes, 4), np.float32)
+    gl = -np.ones((batch, max_boxes), np.int32)
+    for b in range(batch):
+        g = int(rng.integers(1, max_boxes + 1))
+        c = rng.uniform(0.1, 0.9, (g, 2))
+        s = rng.uniform(0.05, 0.5, (g, 2))
+        gt[b, :g] = np.clip(np.concatenate([c - s / 2, c + s / 2], -1), 0, 1).astype(np.float32)
+        gl[b, :g] = rng.integers(1, total_labels, g)
+    return gt, gl
+
+
+def synthetic_dataset(total_items, batch_size, img_size=300, total_labels=21, seed=0):
+    """Finite iterable of (img, gt_boxes, gt_labels) padded batches."""
+    for i in range(0, total_items, batch_size):
+        b = min(batch_size, total_items - i)
+        gt, gl = synthetic_gt(b, total_labels=total_labels, seed=seed + 1000 + i)
+        yield synthetic_images(b, img_size, seed + i), gt, gl
+
+
+def synthetic_weights(model, seed=1, target_frac=0.05):
+    """Seeded random weights for benchmarks (no pretrained weights offline): He-normal conv
+    kernels, BatchNorm gamma 1+-0.1 / beta,mean +-0.1 / var in [0.5,1.5].  The label-head
+    background bias is then calibrated ON THE DEVICE (bisection on the model's own output
+    for one image) so that ~target_frac of the anchors carry a non-background probability
+    above 0.5 -- with purely random weights NMS would have nothing to do."""
+    rng = np.random.default_rng(seed)
+    w = {}
+    for name, shape in model.param_specs:
+        var = name.rsplit("/", 1)[1]
+        if var == "kernel":
+            scale = 0.5 if "label_output" in name else (0.25 if "boxes_output" in name else 1.0)
+            w[name] = (rng.standard_normal(shape) * np.sqrt(2.0 / (shape[0] * shape[1] * shape[2])) * scale).astype(np.float32)
+        elif var == "depthwise_kernel":
+            w[name] = (rng.standard_normal(shape) * np.sqrt(2.0 / 9.0)).astype(np.float32)
+        elif var == "gamma":
+            w[name] = rng.uniform(0.9, 1.1, shape).astype(np.float32)
+        elif var in ("beta", "moving_mean"):
+            w[name] = rng.uniform(-0.1, 0.1, shape).astype(np.float32)
+        elif var == "moving_variance":
+            w[name] = rng.uniform(0.5, 1.5, shape).astype(np.float32)
+        elif var == "scale":
+            w[name] = np.full(shape, 20.0, np.float32)
+        else:
+            w[name] = rng.uniform(-0.05, 0.05, shape).astype(np.float32)
+    model.set_weights(w)
+    _, probs = model(synthetic_images(1, model.img_size, seed=0))
+    logp = np.log(np.maximum(probs[0].double().cpu().numpy(), 1e-300))
+
+    def frac(t):
+        lg = logp.copy()
+        lg[:, 0] += t
+        e = np.exp(lg - lg.max(-1, keepdims=True))
+        p = e / e.sum(-1, keepdims=True)
+        return float(((p.argmax(-1) != 0) & (p.max(-1) > 0.5)).mean())
+    lo, hi = -50.0, 50.0
+    for _ in range(40):
+        mid = 0.5 * (lo + hi)
+        if frac(mid) > target_frac:
+            lo = mid
+        else:
+            hi = mid
+    L = model.total_labels
+    upd = {}
+    for i in range(1, 7):
+        b = w["%d_conv_label_output/bias" % i].copy()
+        b[0::L] += np.float32(0.5 * (lo + hi))
+        w["%d_conv_label_output/bias" % i] = b
+        upd["%d_conv_label_output/bias" % i] = b
+    model.set_weights(upd)
+    return w
