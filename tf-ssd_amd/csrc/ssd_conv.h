@@ -19,6 +19,12 @@ struct ConvParams {
     int K, Kpad, Npad;
     long M;
     long out_batch_stride, out_pixel_stride;
+    // optional second destination: output channels n >= n_split go to out2 (column n - n_split)
+    // with their own strides -- the fused SSD label+box head conv of one level.
+    int n_split;           // 0: single destination
+    float* out2;
+    long out2_batch_stride, out2_pixel_stride;
+    int vec_store2;
     int act;
     int vec_store;         // 1: float4 stores are aligned
     int split_k;           // >1: partial sums to `partial` [split][M][Cout], epilogue deferred
@@ -34,6 +40,8 @@ const char* conv_config_name(int cfg);
 // true if config `cfg` can run these parameters (alignment / shape constraints).
 bool conv_config_valid(int cfg, const ConvParams& p);
 int conv_pick_config(const ConvParams& p);                 // heuristic
+long conv_grid_blocks(int cfg, const ConvParams& p);       // blocks of the un-split grid
+int conv_k_tiles(int cfg, const ConvParams& p);            // K tiles per block without split
 int conv_launch(const ConvParams& p, int cfg, hipStream_t st);
 size_t conv_splitk_workspace_floats(const ConvParams& p, int cfg);
 

@@ -168,6 +168,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvParams p) {
         const int b = (int)(m / HoWo);
         const long pix = m - (long)b * HoWo;
         float* orow = p.out + (long)b * p.out_batch_stride + pix * p.out_pixel_stride;
+        float* orow2 = p.n_split ? p.out2 + (long)b * p.out2_batch_stride + pix * p.out2_pixel_stride - p.n_split : nullptr;
 #pragma unroll
         for (int ni = 0; ni < NT; ++ni) {
             const int n = n0 + (wn * NT + ni) * 16 + (lane >> 4) * 4;
@@ -183,15 +184,12 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvParams p) {
                 }
                 continue;
             }
-            if (n + 3 < p.Cout) {
-                if (p.scale) {
-                    const f32x4 sc = *reinterpret_cast<const f32x4*>(p.scale + n);
-                    v = v * sc;
-                }
-                if (p.shift) {
-                    const f32x4 sh = *reinterpret_cast<const f32x4*>(p.shift + n);
-                    v = v + sh;
-                }
+            const bool full = n + 3 < p.Cout;
+            const bool side2 = p.n_split && n >= p.n_split;
+            const bool straddle = p.n_split && n < p.n_split && n + 3 >= p.n_split;
+            if (full && !straddle) {
+                if (p.scale) v = v * *reinterpret_cast<const f32x4*>(p.scale + n);
+                if (p.shift) v = v + *reinterpret_cast<const f32x4*>(p.shift + n);
 #pragma unroll
                 for (int j = 0; j < 4; ++j) v[j] = apply_act(v[j], p.act);
                 if (p.residual) {
@@ -202,10 +200,11 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvParams p) {
                         for (int j = 0; j < 4; ++j) v[j] += rr[j];
                     }
                 }
-                if (p.vec_store) {
-                    *reinterpret_cast<f32x4*>(orow + n) = v;
+                float* dst = (side2 ? orow2 : orow) + n;
+                if ((side2 ? p.vec_store2 : p.vec_store) && ((((uintptr_t)dst) & 15) == 0)) {
+                    *reinterpret_cast<f32x4*>(dst) = v;
                 } else {
-                    orow[n] = v[0]; orow[n + 1] = v[1]; orow[n + 2] = v[2]; orow[n + 3] = v[3];
+                    dst[0] = v[0]; dst[1] = v[1]; dst[2] = v[2]; dst[3] = v[3];
                 }
             } else {
                 for (int j = 0; j < 4; ++j) {
@@ -215,7 +214,8 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvParams p) {
                     if (p.shift) t = t + p.shift[n + j];
                     t = apply_act(t, p.act);
                     if (p.residual) t += p.residual[m * p.Cout + n + j];
-                    orow[n + j] = t;
+                    float* drow = (p.n_split && n + j >= p.n_split) ? orow2 : orow;
+                    drow[n + j] = t;
                 }
             }
         }
@@ -237,7 +237,10 @@ __global__ void splitk_reduce_kernel(const ConvParams p) {
         if (p.residual) t += p.residual[e];
         const int b = (int)(m / HoWo);
         const long pix = m - (long)b * HoWo;
-        p.out[(long)b * p.out_batch_stride + pix * p.out_pixel_stride + n] = t;
+        if (p.n_split && n >= p.n_split)
+            p.out2[(long)b * p.out2_batch_stride + pix * p.out2_pixel_stride + (n - p.n_split)] = t;
+        else
+            p.out[(long)b * p.out_batch_stride + pix * p.out_pixel_stride + n] = t;
     }
 }
 
@@ -294,6 +297,94 @@ __global__ __launch_bounds__(256) void conv_direct_kernel(const ConvParams p) {
     }
 }
 
+// RGB stem (Cin = 3, 3x3: Conv1 of MobileNetV2, conv1_1 of VGG16): K = 27 is too short
+// for the MFMA tiles, and the layer is bound by its output write.  One thread = PX output
+// pixels x 32 output channels; the 27 x 32 weight slab sits in LDS and is read with
+// wave-uniform (broadcast) 16-byte reads; 32 accumulators per pixel stay in registers and
+// leave as eight 16-byte stores (each lane writes its pixel's 128 contiguous bytes).
+template <int PX>
+__global__ __launch_bounds__(256) void conv_stem_kernel(const ConvParams p) {
+    __shared__ __attribute__((aligned(16))) float wl[27 * 32];
+    const int cg = blockIdx.y * 32;                    // output-channel group
+    for (int e = threadIdx.x; e < 27 * 32; e += 256) {
+        const int k = e >> 5, n = cg + (e & 31);
+        wl[e] = n < p.Cout ? p.w[(long)n * p.Kpad + k] : 0.f;
+    }
+    __syncthreads();
+    const int HoWo = p.Ho * p.Wo;
+    for (long base = (long)blockIdx.x * 256 * PX; base < p.M; base += (long)gridDim.x * 256 * PX) {
+        f32x4 acc[PX][8];
+        long mm[PX];
+        const float* xb[PX];
+        int iy0[PX], ix0[PX];
+#pragma unroll
+        for (int q = 0; q < PX; ++q) {
+            mm[q] = base + q * 256 + threadIdx.x;
+            const long m = mm[q] < p.M ? mm[q] : 0;
+            const int b = (int)(m / HoWo);
+            const int pix = (int)(m - (long)b * HoWo);
+            const int oy = pix / p.Wo, ox = pix - oy * p.Wo;
+            iy0[q] = oy * p.stride - p.pad_t;
+            ix0[q] = ox * p.stride - p.pad_l;
+            xb[q] = p.in + (long)b * p.H * p.W * 3;
+#pragma unroll
+            for (int c = 0; c < 8; ++c) acc[q][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll 1
+        for (int tap = 0; tap < 9; ++tap) {
+            {
+                const int ky = tap / 3, kx = tap - ky * 3;
+                float x[PX][3];
+#pragma unroll
+                for (int q = 0; q < PX; ++q) {
+                    const int iy = iy0[q] + ky * p.dil, ix = ix0[q] + kx * p.dil;
+                    x[q][0] = x[q][1] = x[q][2] = 0.f;
+                    if ((unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W) {
+                        const float* xp = xb[q] + ((long)iy * p.W + ix) * 3;
+                        x[q][0] = xp[0]; x[q][1] = xp[1]; x[q][2] = xp[2];
+                    }
+                }
+#pragma unroll
+                for (int ci = 0; ci < 3; ++ci) {
+                    const float* wk = wl + (tap * 3 + ci) * 32;
+#pragma unroll
+                    for (int c = 0; c < 8; ++c) {
+                        const f32x4 w4 = *reinterpret_cast<const f32x4*>(wk + c * 4);
+#pragma unroll
+                        for (int q = 0; q < PX; ++q) {
+                            acc[q][c][0] = fmaf(x[q][ci], w4[0], acc[q][c][0]);
+                            acc[q][c][1] = fmaf(x[q][ci], w4[1], acc[q][c][1]);
+                            acc[q][c][2] = fmaf(x[q][ci], w4[2], acc[q][c][2]);
+                            acc[q][c][3] = fmaf(x[q][ci], w4[3], acc[q][c][3]);
+                        }
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < PX; ++q) {
+            if (mm[q] >= p.M) continue;
+            const int b = (int)(mm[q] / HoWo);
+            const long pix = mm[q] - (long)b * HoWo;
+            float* orow = p.out + (long)b * p.out_batch_stride + pix * p.out_pixel_stride + cg;
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                f32x4 v = acc[q][c];
+                if (p.scale) v = v * *reinterpret_cast<const f32x4*>(p.scale + cg + c * 4);
+                if (p.shift) v = v + *reinterpret_cast<const f32x4*>(p.shift + cg + c * 4);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] = apply_act(v[j], p.act);
+                *reinterpret_cast<f32x4*>(orow + c * 4) = v;
+            }
+        }
+    }
+}
+
+static bool stem_ok(const ConvParams& p) {
+    return p.Cin == 3 && p.kh == 3 && p.kw == 3 && (p.Cout % 32) == 0 && !p.residual && !p.n_split && p.vec_store &&
+           (!p.scale || (((uintptr_t)p.scale & 15) == 0)) && (!p.shift || (((uintptr_t)p.shift & 15) == 0));
+}
+
 // HWIO [K][Cout] -> packed [Npad][Kpad], zero padded.
 __global__ void pack_weights_kernel(const float* __restrict__ hwio, int K, int Cout, int Kpad, int Npad,
                                     float* __restrict__ packed) {
@@ -331,6 +422,12 @@ static const ConvCfg kCfgs[] = {
     CFG(1, 2, 1, 4, 32),   // 13: 16 x 128
     CFG(4, 2, 4, 1, 32),   // 14: 256 x 32
     CFG(2, 8, 2, 2, 32),   // 15: 64 x 256
+    CFG(2, 7, 4, 1, 32),   // 16: 128 x 112 (fused heads, A*(L+4) = 100)
+    CFG(2, 5, 2, 2, 32),   // 17: 64 x 160  (fused heads, 150)
+    CFG(1, 7, 4, 1, 32),   // 18: 64 x 112
+    CFG(1, 5, 2, 2, 32),   // 19: 32 x 160
+    CFG(4, 3, 2, 2, 32),   // 20: 128 x 96 (64 x 48 wave tiles)
+    CFG(4, 6, 2, 2, 32),   // 21: 128 x 192
 };
 constexpr int kNumMfmaCfgs = sizeof(kCfgs) / sizeof(kCfgs[0]);
 constexpr int kDirectCfg = kNumMfmaCfgs;       // last config id = VALU direct kernel
@@ -377,6 +474,16 @@ int conv_pick_config(const ConvParams& p) {
     return best;
 }
 
+long conv_grid_blocks(int cfg, const ConvParams& p) {
+    if (cfg < 0 || cfg >= kNumMfmaCfgs) return 0;
+    const ConvCfg& g = kCfgs[cfg];
+    return ((p.M + g.BM - 1) / g.BM) * ((p.Cout + g.BN - 1) / g.BN);
+}
+int conv_k_tiles(int cfg, const ConvParams& p) {
+    if (cfg < 0 || cfg >= kNumMfmaCfgs) return 0;
+    return (p.K + kCfgs[cfg].BK - 1) / kCfgs[cfg].BK;
+}
+
 size_t conv_splitk_workspace_floats(const ConvParams& p, int) {
     return p.split_k > 1 ? (size_t)p.split_k * p.M * p.Cout : 0;
 }
@@ -387,6 +494,14 @@ int conv_launch(const ConvParams& p, int cfg, hipStream_t st) {
         set_error("conv2d: config %d (%s) cannot run Cin=%d k=%dx%d stride=%d", cfg, conv_config_name(cfg),
                   p.Cin, p.kh, p.kw, p.stride);
         return SSD_E_UNSUPPORTED;
+    }
+    if (cfg == kDirectCfg && stem_ok(p)) {
+        constexpr int PX = 2;
+        const long blocks = cdiv(p.M, 256 * PX);
+        dim3 grid((unsigned)(blocks < 65535 ? blocks : 65535), p.Cout / 32);
+        hipLaunchKernelGGL(conv_stem_kernel<PX>, grid, dim3(256), 0, st, p);
+        SSD_LAUNCH_CHECK();
+        return SSD_OK;
     }
     if (cfg == kDirectCfg) {
         const long total = p.M * ((p.Cout + 3) / 4);

@@ -40,10 +40,13 @@ struct Layer {
     int H = 0, W = 0, Cin = 0, Ho = 0, Wo = 0, Cout = 0;
     int kh = 1, kw = 1, stride = 1, dil = 1, pt = 0, pl = 0, pb = 0, pr = 0, act = 0;
     int p_kernel = -1, p_bias = -1, p_bn = -1;  // p_bn: index of gamma (beta, mean, var follow)
+    int p_kernel2 = -1, p_bias2 = -1, Cout1 = 0; // fused head conv: second (boxes) kernel/bias, label width
     int p_gamma = -1;                           // l2norm scale
-    // head routing (floats): level offset, batch stride, pixel stride; head_kind 1 = labels, 2 = boxes
+    // head routing (floats): level offset, batch stride, pixel stride for the label part
+    // (head_*) and the box part (head2_*); head_kind 3 = fused label+box head conv of one level
     int head_kind = 0;
     long head_off = 0, head_bs = 0, head_ps = 0;
+    long head2_off = 0, head2_bs = 0, head2_ps = 0;
     // derived at finalize
     float* packed = nullptr;
     float* scale = nullptr;
@@ -210,19 +213,36 @@ struct Builder {
             off += (long)t.H * t.W * (net.n_ars[i] + 1);
         }
         net.num_priors = (int)off;
+        // One fused conv per level: the label conv (A*L channels) and the box conv (A*4) read the
+        // same feature map, so they run as ONE implicit GEMM with N = A*(L+4); the epilogue
+        // routes columns < A*L to the concatenated label buffer and the rest to the box buffer.
         for (size_t i = 0; i < feats.size(); ++i) {
             const int A = net.n_ars[i] + 1;
             const std::string idx = std::to_string(i + 1);
-            for (int which = 1; which <= 2; ++which) {
-                const int comp = which == 1 ? net.L : 4;
-                conv(idx + (which == 1 ? "_conv_label_output" : "_conv_boxes_output"), "", feats[i], A * comp,
-                     3, 1, 1, 1, "", true, SSD_ACT_NONE);
-                Layer& l = net.layers.back();
-                l.head_kind = which;
-                l.head_off = net.level_off[i] * comp;
-                l.head_bs = (long)net.num_priors * comp;
-                l.head_ps = (long)A * comp;
-            }
+            const Tensor ti = net.tensors[feats[i]];
+            Layer l;
+            l.name = idx + "_conv_heads";
+            l.kind = LK_CONV;
+            l.in = feats[i];
+            l.H = ti.H; l.W = ti.W; l.Cin = ti.C;
+            l.Cout1 = A * net.L;
+            l.Cout = A * (net.L + 4);
+            l.kh = l.kw = 3; l.stride = 1; l.dil = 1; l.act = SSD_ACT_NONE;
+            pads(ti.H, 3, 1, 1, 1, &l.pt, &l.pb);
+            pads(ti.W, 3, 1, 1, 1, &l.pl, &l.pr);
+            l.Ho = ti.H; l.Wo = ti.W;
+            l.p_kernel = add_param(idx + "_conv_label_output/kernel", {3, 3, ti.C, A * net.L});
+            l.p_bias = add_param(idx + "_conv_label_output/bias", {A * net.L});
+            l.p_kernel2 = add_param(idx + "_conv_boxes_output/kernel", {3, 3, ti.C, A * 4});
+            l.p_bias2 = add_param(idx + "_conv_boxes_output/bias", {A * 4});
+            l.head_kind = 3;
+            l.head_off = net.level_off[i] * net.L;
+            l.head_bs = (long)net.num_priors * net.L;
+            l.head_ps = (long)A * net.L;
+            l.head2_off = net.level_off[i] * 4;
+            l.head2_bs = (long)net.num_priors * 4;
+            l.head2_ps = (long)A * 4;
+            net.layers.push_back(l);
         }
         Layer sm;
         sm.name = "conf";
@@ -330,9 +350,14 @@ static ConvParams layer_conv_params(const ssd_net& net, const Layer& l, int B, c
         p.out_pixel_stride = l.Cout;
         p.out_batch_stride = (long)l.Ho * l.Wo * l.Cout;
     } else {
-        p.out = (l.head_kind == 1 ? probs_out : deltas_out) + l.head_off;
+        p.out = probs_out + l.head_off;
         p.out_pixel_stride = l.head_ps;
         p.out_batch_stride = l.head_bs;
+        p.n_split = l.Cout1;
+        p.out2 = deltas_out + l.head2_off;
+        p.out2_pixel_stride = l.head2_ps;
+        p.out2_batch_stride = l.head2_bs;
+        p.vec_store2 = (p.out2_pixel_stride % 4 == 0) && (p.out2_batch_stride % 4 == 0);
     }
     p.vec_store = (((uintptr_t)p.out & 15) == 0) && (p.out_pixel_stride % 4 == 0) && (p.out_batch_stride % 4 == 0);
     return p;
@@ -369,38 +394,63 @@ static int dev_alloc(ssd_net& net, size_t floats, float** out) {
     return SSD_OK;
 }
 
-// Time each valid tile configuration of every conv layer on the device and keep the best.
+// Time each valid (tile configuration, split-K factor) of every conv layer on the device and
+// keep the best.  Split-K is tried only where the plain grid cannot fill the 256 CUs.
 static int autotune(ssd_net& net, int B, hipStream_t st) {
     hipEvent_t e0, e1;
     SSD_HIP(hipEventCreate(&e0));
     SSD_HIP(hipEventCreate(&e1));
-    // scratch outputs for head convs
-    float *d = nullptr, *pr = nullptr;
+    float *d = nullptr, *pr = nullptr;     // scratch outputs for the head convs
     SSD_HIP(hipMalloc((void**)&d, (size_t)B * net.num_priors * 4 * sizeof(float)));
     SSD_HIP(hipMalloc((void**)&pr, (size_t)B * net.num_priors * net.L * sizeof(float)));
+    static const int kSplits[] = {1, 2, 4, 8, 16};
+    // split-K workspace: the largest [split][M][Cout] slab any candidate may need
+    size_t ws_floats = 0;
+    for (auto& l : net.layers) {
+        if (l.kind != LK_CONV) continue;
+        const size_t mc = (size_t)B * l.Ho * l.Wo * l.Cout;
+        if (mc <= (size_t)4 << 20) ws_floats = std::max(ws_floats, mc * 16);
+    }
+    if (ws_floats > net.splitk_floats) {
+        if (net.splitk_ws) (void)hipFree(net.splitk_ws);
+        net.splitk_ws = nullptr;
+        SSD_HIP(hipMalloc((void**)&net.splitk_ws, ws_floats * sizeof(float)));
+        net.splitk_floats = ws_floats;
+    }
     int rc = SSD_OK;
     for (auto& l : net.layers) {
         if (l.kind != LK_CONV) continue;
         const float* in = net.tensors[l.in].dev;
         float* out = l.out >= 0 ? net.tensors[l.out].dev : nullptr;
         const float* res = l.res >= 0 ? net.tensors[l.res].dev : nullptr;
-        ConvParams p = layer_conv_params(net, l, B, in, out, res, d, pr);
         float best = 1e30f;
-        int best_cfg = -1;
-        for (int c = 0; c < conv_num_configs(); ++c) {
-            if (!conv_config_valid(c, p)) continue;
-            if (c == conv_num_configs() - 1 && best_cfg >= 0) continue;   // direct only as a last resort
-            const int reps = 3;
-            rc = conv_launch(p, c, st);     // warm-up
-            if (rc) break;
-            (void)hipEventRecord(e0, st);
-            for (int r = 0; r < reps && !rc; ++r) rc = conv_launch(p, c, st);
-            (void)hipEventRecord(e1, st);
-            if (rc) break;
-            SSD_HIP(hipEventSynchronize(e1));
-            float ms = 0.f;
-            (void)hipEventElapsedTime(&ms, e0, e1);
-            if (ms < best) { best = ms; best_cfg = c; }
+        int best_cfg = -1, best_split = 1;
+        for (int c = 0; c < conv_num_configs() && !rc; ++c) {
+            for (int si = 0; si < 5 && !rc; ++si) {
+                const int split = kSplits[si];
+                l.split_k = split;
+                ConvParams p = layer_conv_params(net, l, B, in, out, res, d, pr);
+                if (!conv_config_valid(c, p)) break;
+                const bool direct = (c == conv_num_configs() - 1);
+                if (direct && (best_cfg >= 0 || split > 1)) break;     // direct only as a last resort
+                if (split > 1) {
+                    const long blocks = conv_grid_blocks(c, p);
+                    const int nkt = conv_k_tiles(c, p);
+                    if (blocks > 384 || nkt < 4 * split) break;
+                    if ((size_t)split * p.M * p.Cout > net.splitk_floats) break;
+                }
+                const int reps = 3;
+                rc = conv_launch(p, c, st);     // warm-up
+                if (rc) break;
+                (void)hipEventRecord(e0, st);
+                for (int r = 0; r < reps && !rc; ++r) rc = conv_launch(p, c, st);
+                (void)hipEventRecord(e1, st);
+                if (rc) break;
+                SSD_HIP(hipEventSynchronize(e1));
+                float ms = 0.f;
+                (void)hipEventElapsedTime(&ms, e0, e1);
+                if (ms < best) { best = ms; best_cfg = c; best_split = split; }
+            }
         }
         if (rc) break;
         if (best_cfg < 0) {
@@ -409,6 +459,7 @@ static int autotune(ssd_net& net, int B, hipStream_t st) {
             break;
         }
         l.cfg = best_cfg;
+        l.split_k = best_split;
     }
     (void)hipFree(d);
     (void)hipFree(pr);
@@ -502,8 +553,16 @@ int ssd_net_finalize(ssd_net* net, int max_batch) {
             const int K = l.kh * l.kw * l.Cin;
             int rc = dev_alloc(*net, (size_t)conv_kpad(K) * conv_npad(l.Cout), &l.packed);
             if (rc) return rc;
-            rc = launch_pack_weights(net->params[l.p_kernel].dev, K, l.Cout, conv_kpad(K), conv_npad(l.Cout),
-                                     l.packed, st);
+            if (l.p_kernel2 < 0) {
+                rc = launch_pack_weights(net->params[l.p_kernel].dev, K, l.Cout, conv_kpad(K), conv_npad(l.Cout),
+                                         l.packed, st);
+            } else {    // fused head: rows [0, Cout1) = label kernel, [Cout1, Cout) = box kernel
+                SSD_HIP(hipMemsetAsync(l.packed, 0, (size_t)conv_kpad(K) * conv_npad(l.Cout) * sizeof(float), st));
+                rc = launch_pack_weights(net->params[l.p_kernel].dev, K, l.Cout1, conv_kpad(K), l.Cout1, l.packed, st);
+                if (!rc)
+                    rc = launch_pack_weights(net->params[l.p_kernel2].dev, K, l.Cout - l.Cout1, conv_kpad(K),
+                                             l.Cout - l.Cout1, l.packed + (size_t)l.Cout1 * conv_kpad(K), st);
+            }
             if (rc) return rc;
         }
         if (l.kind == LK_CONV || l.kind == LK_DW) {
@@ -514,6 +573,13 @@ int ssd_net_finalize(ssd_net* net, int max_batch) {
                 rc = launch_fold_bn(net->params[l.p_bn].dev, net->params[l.p_bn + 1].dev, net->params[l.p_bn + 2].dev,
                                     net->params[l.p_bn + 3].dev, 1e-3f, l.Cout, l.scale, l.shift, st);
                 if (rc) return rc;
+            } else if (l.p_bias2 >= 0) {
+                int rc = dev_alloc(*net, l.Cout, &l.shift);
+                if (rc) return rc;
+                SSD_HIP(hipMemcpyAsync(l.shift, net->params[l.p_bias].dev, (size_t)l.Cout1 * sizeof(float),
+                                       hipMemcpyDeviceToDevice, st));
+                SSD_HIP(hipMemcpyAsync(l.shift + l.Cout1, net->params[l.p_bias2].dev,
+                                       (size_t)(l.Cout - l.Cout1) * sizeof(float), hipMemcpyDeviceToDevice, st));
             } else if (l.p_bias >= 0) {
                 l.shift = net->params[l.p_bias].dev;     // bias-only epilogue: scale == 1
             }
@@ -670,7 +736,11 @@ const char* ssd_net_layer_kind(const ssd_net* net, int i) {
 }
 const char* ssd_net_layer_config(const ssd_net* net, int i) {
     if (!net || i < 0 || i >= (int)net->layers.size() || net->layers[i].kind != LK_CONV) return "";
-    return conv_config_name(net->layers[i].cfg);
+    static thread_local char buf[64];
+    const Layer& l = net->layers[i];
+    if (l.split_k > 1) snprintf(buf, sizeof(buf), "%s/s%d", conv_config_name(l.cfg), l.split_k);
+    else snprintf(buf, sizeof(buf), "%s", conv_config_name(l.cfg));
+    return buf;
 }
 double ssd_net_layer_flops(const ssd_net* net, int i, int B) {
     if (!net || i < 0 || i >= (int)net->layers.size()) return 0;
