@@ -193,6 +193,11 @@ int ssd_net_set_param(ssd_net* net, const char* name, const float* host_data, si
 int ssd_net_get_param(const ssd_net* net, const char* name, float* host_out, size_t count);
 /* Fold BN, pack weights for the MFMA kernels, size the arena for `max_batch`. */
 int ssd_net_finalize(ssd_net* net, int max_batch);
+/* Tile-configuration table chosen by finalize's on-device autotune, as text (one
+ * "layer config split_k" line per conv).  get returns the length (buf may be NULL);
+ * set installs a table that the next finalize uses instead of re-tuning (if complete/valid). */
+long ssd_net_get_tuning(const ssd_net* net, char* buf, size_t cap);
+int ssd_net_set_tuning(ssd_net* net, const char* text);
 int ssd_net_num_priors(const ssd_net* net);
 int ssd_net_feature_map_size(const ssd_net* net, int level);
 

@@ -1,0 +1,131 @@
+"""CPU tests of the host side: the C-ABI library loads and exports every symbol
+include/ssd_hip.h declares (no compute calls without a GPU), host logic of the drop-in
+modules, and the N>1 sharding/gather plumbing with world-size-2 gloo processes."""
+import ctypes
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_symbols():
+    text = open(os.path.join(REPO, "include", "ssd_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(ssd_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    import ssd_hip
+    assert os.path.exists(ssd_hip.LIB_PATH), "build libssd_hip.so first (__graft_entry__.build())"
+    lib = ctypes.CDLL(ssd_hip.LIB_PATH)
+    names = _declared_symbols()
+    assert len(names) >= 45
+    for n in names:
+        assert hasattr(lib, n), "missing export %s" % n
+    # and the ctypes table covers all of them
+    assert set(names) <= set(ssd_hip._SIGNATURES), set(names) - set(ssd_hip._SIGNATURES)
+    l = ssd_hip.lib()
+    assert b"gfx950" in l.ssd_version()
+
+
+def test_pure_host_entry_points():
+    import ssd_hip
+    l = ssd_hip.lib()
+    b, a = ctypes.c_int(), ctypes.c_int()
+    assert l.ssd_same_pads(10, 3, 2, 1, ctypes.byref(b), ctypes.byref(a)) == 5 and (b.value, a.value) == (0, 1)
+    assert l.ssd_same_pads(19, 3, 1, 6, ctypes.byref(b), ctypes.byref(a)) == 19 and (b.value, a.value) == (6, 6)
+    assert l.ssd_conv_out_size(5, 3, 1, 1, 0, 0) == 3 and l.ssd_conv_out_size(5, 3, 0, 1, 0, 0) == 0
+    assert l.ssd_conv_packed_weight_floats(3, 3, 576, 84) == 5184 * 96
+    fm = (ctypes.c_int * 6)(19, 10, 5, 3, 2, 1)
+    na = (ctypes.c_int * 6)(3, 5, 5, 5, 3, 3)
+    assert l.ssd_priors_count(fm, na, 6) == 2268
+    assert l.ssd_conv_num_configs() >= 10 and l.ssd_conv_config_name(0).startswith(b"mfma_")
+    # graph construction needs no device
+    net = l.ssd_net_create(ssd_hip.MOBILENET_V2, 300, 6, na, 21)
+    assert net and l.ssd_net_num_priors(net) == 2268 and l.ssd_net_num_params(net) == 300
+    assert l.ssd_net_forward(net, None, 1, None, None, None) == -4          # not finalized
+    assert b"finalize" in l.ssd_last_error()
+    assert l.ssd_net_set_param(net, b"nope", (ctypes.c_float * 1)(), 1) == -1
+    l.ssd_net_destroy(net)
+    assert not l.ssd_net_create(7, 300, 6, na, 21) and b"bad arguments" in l.ssd_last_error()
+
+
+def test_no_cpu_fallback():
+    """Without a GPU every compute entry point of the Python surface must raise."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    import ssd_hip
+    from utils import bbox_utils
+    with pytest.raises(ssd_hip.SsdHipError):
+        bbox_utils.generate_prior_boxes([19, 10, 5, 3, 2, 1], [[1., 2., .5]] * 6)
+    with pytest.raises(ssd_hip.SsdHipError):
+        bbox_utils.get_bboxes_from_deltas(np.zeros((4, 4), np.float32), np.zeros((1, 4, 4), np.float32))
+
+
+def test_hyper_params_semantics():
+    from utils import train_utils, io_utils
+    hp = train_utils.get_hyper_params("mobilenet_v2")
+    assert hp is train_utils.SSD["mobilenet_v2"]                     # mutated global, like the reference
+    assert hp["feature_map_shapes"] == [19, 10, 5, 3, 2, 1] and hp["variances"] == [0.1, 0.1, 0.2, 0.2]
+    assert train_utils.get_hyper_params("vgg16", img_size=512, nope=3, iou_threshold=0)["img_size"] == 512
+    assert train_utils.SSD["vgg16"]["iou_threshold"] == 0.5 and "nope" not in train_utils.SSD["vgg16"]
+    train_utils.SSD["vgg16"]["img_size"] = 300
+    assert [train_utils.scheduler(e) for e in (0, 99, 100, 124, 125)] == [1e-3, 1e-3, 1e-4, 1e-4, 1e-5]
+    assert train_utils.get_step_size(4952, 32) == 155
+    args = io_utils.handle_args([])
+    assert args.backbone == "mobilenet_v2" and args.handle_gpu is False
+    assert io_utils.handle_args(["-handle-gpu", "--backbone", "vgg16"]).backbone == "vgg16"
+    with pytest.raises(AssertionError):
+        io_utils.is_valid_backbone("resnet")
+    assert io_utils.get_log_path("vgg16").startswith("logs/vgg16/")
+
+
+def test_shard_range():
+    import parallel
+    for n in (0, 1, 7, 64, 4952):
+        for world in (1, 2, 3, 8):
+            spans = [parallel.shard_range(n, r, world) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(spans[i][1] == spans[i + 1][0] for i in range(world - 1))
+            sizes = [b - a for a, b in spans]
+            assert max(sizes) - min(sizes) <= 1
+
+
+_WORKER = r'''
+import os, sys
+sys.path.insert(0, os.path.join(%(repo)r, "tf-ssd_amd"))
+import torch, parallel
+rank, local, world = parallel.init_distributed("gloo")
+assert world == 2
+n, T = 5, 3
+lo, hi = parallel.shard_range(n, rank, world)
+idx = torch.arange(lo, hi, dtype=torch.float32)
+boxes = idx.view(-1, 1, 1).expand(-1, T, 4).contiguous()
+labels = (idx.view(-1, 1) + 100).expand(-1, T).contiguous()
+scores = (idx.view(-1, 1) + 200).expand(-1, T).contiguous()
+b, l, s = parallel.gather_detections(boxes, labels, scores, n_total=n)
+assert b.shape == (n, T, 4) and torch.equal(b[:, 0, 0], torch.arange(n, dtype=torch.float32))
+assert torch.equal(l[:, 0], torch.arange(n, dtype=torch.float32) + 100)
+assert torch.equal(s[:, 2], torch.arange(n, dtype=torch.float32) + 200)
+assert parallel.max_over_ranks(1.0 + rank) == 2.0
+torch.distributed.barrier()
+torch.distributed.destroy_process_group()
+print("rank", rank, "ok")
+'''
+
+
+def test_two_process_gloo_gather(tmp_path):
+    script = tmp_path / "worker.py"
+    script.write_text(_WORKER % {"repo": REPO})
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                          "--master-addr", "127.0.0.1", "--master-port", "29533", str(script)],
+                         env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "rank 0 ok" in out.stdout and "rank 1 ok" in out.stdout

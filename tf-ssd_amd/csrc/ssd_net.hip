@@ -6,6 +6,7 @@
 // Reference graphs: models/ssd_mobilenet_v2.py:7-35 (+ [3P] keras-applications 1.0.8
 // MobileNetV2), models/ssd_vgg16.py:33-97, models/header.py:43-67.
 #include <algorithm>
+#include <cstring>
 #include <map>
 #include <memory>
 #include <string>
@@ -83,6 +84,7 @@ struct ssd_net {
     void* nms_ws = nullptr;
     size_t nms_ws_bytes = 0;
     // optional per-layer hipEvent timing of forward()/predict() (bench.py roofline leg)
+    std::map<std::string, std::pair<std::string, int>> preset;   // layer -> (config name, split_k)
     bool timing = false;
     std::vector<std::vector<hipEvent_t>> timing_events;   // one vector of (layers + 2) events per forward
 
@@ -601,10 +603,70 @@ int ssd_net_finalize(ssd_net* net, int max_batch) {
     net->max_batch = max_batch;
     // pick tile configurations on the device
     for (auto& l : net->layers) { l.cfg = -1; l.split_k = 1; }
-    int rc = autotune(*net, max_batch, st);
+    // a complete, valid preset (ssd_net_set_tuning) replaces the on-device autotune
+    bool preset_ok = !net->preset.empty();
+    size_t ws_need = 0;
+    for (auto& l : net->layers) {
+        if (l.kind != LK_CONV || !preset_ok) continue;
+        auto it = net->preset.find(l.name);
+        if (it == net->preset.end()) { preset_ok = false; break; }
+        int cfg = -1;
+        for (int c = 0; c < conv_num_configs(); ++c)
+            if (it->second.first == conv_config_name(c)) cfg = c;
+        if (cfg < 0) { preset_ok = false; break; }
+        l.cfg = cfg;
+        l.split_k = it->second.second;
+        ConvParams p = layer_conv_params(*net, l, max_batch, net->tensors[l.in].dev,
+                                         l.out >= 0 ? net->tensors[l.out].dev : nullptr, nullptr,
+                                         net->arena, net->arena);
+        if (!conv_config_valid(cfg, p)) { preset_ok = false; break; }
+        if (l.split_k > 1) ws_need = std::max(ws_need, (size_t)l.split_k * p.M * p.Cout);
+    }
+    int rc = SSD_OK;
+    if (preset_ok) {
+        if (ws_need > net->splitk_floats) {
+            if (net->splitk_ws) (void)hipFree(net->splitk_ws);
+            net->splitk_ws = nullptr;
+            SSD_HIP(hipMalloc((void**)&net->splitk_ws, ws_need * sizeof(float)));
+            net->splitk_floats = ws_need;
+        }
+    } else {
+        for (auto& l : net->layers) { l.cfg = -1; l.split_k = 1; }
+        rc = autotune(*net, max_batch, st);
+    }
     if (rc) return rc;
     SSD_HIP(hipDeviceSynchronize());
     net->finalized = true;
+    return SSD_OK;
+}
+
+// Tuning table as text, one "layer config split_k" line per conv layer.
+long ssd_net_get_tuning(const ssd_net* net, char* buf, size_t cap) {
+    if (!net) return SSD_E_INVALID;
+    std::string out;
+    for (const auto& l : net->layers)
+        if (l.kind == LK_CONV && l.cfg >= 0)
+            out += l.name + " " + conv_config_name(l.cfg) + " " + std::to_string(l.split_k) + "\n";
+    if (buf && cap > out.size()) memcpy(buf, out.c_str(), out.size() + 1);
+    return (long)out.size();
+}
+
+int ssd_net_set_tuning(ssd_net* net, const char* text) {
+    SSD_CHECK_ARG(net && text, "ssd_net_set_tuning: NULL argument");
+    net->preset.clear();
+    std::string s(text);
+    size_t pos = 0;
+    while (pos < s.size()) {
+        size_t e = s.find('\n', pos);
+        if (e == std::string::npos) e = s.size();
+        const std::string line = s.substr(pos, e - pos);
+        pos = e + 1;
+        char name[128], cfg[128];
+        int split = 1;
+        if (sscanf(line.c_str(), "%127s %127s %d", name, cfg, &split) == 3 && split >= 1 && split <= 64)
+            net->preset[name] = {cfg, split};
+    }
+    net->finalized = false;
     return SSD_OK;
 }
 

@@ -3,6 +3,7 @@ native graph runner (``ssd_net_*`` in include/ssd_hip.h).  PyTorch is the device
 stream provider only; weights live in the native net, keyed by the Keras variable names
 (``<layer>/<variable>``) in Keras layouts."""
 import ctypes
+import os
 
 import numpy as np
 import torch
@@ -93,8 +94,22 @@ class SSDModel(object):
             raise RuntimeError("model has no weights: call set_weights()/load_weights() first")
         want = max(B, self._max_batch or 0)
         if self._finalized_for < want:
-            _h.check(_h.lib().ssd_net_finalize(self._net, want), "ssd_net_finalize")
+            lib = _h.lib()
+            # optional tuning cache (env SSD_HIP_TUNE_CACHE = directory): skip the on-device
+            # autotune when a table for this (backbone, size, labels, batch) was saved before
+            cache = os.environ.get("SSD_HIP_TUNE_CACHE")
+            path = None
+            if cache:
+                path = os.path.join(cache, "%s_%d_%d_b%d.tune" % (self.backbone, self.img_size, self.total_labels, want))
+                if os.path.exists(path):
+                    with open(path, "rb") as f:
+                        _h.check(lib.ssd_net_set_tuning(self._net, f.read()), "ssd_net_set_tuning")
+            _h.check(lib.ssd_net_finalize(self._net, want), "ssd_net_finalize")
             self._finalized_for = want
+            if path and not os.path.exists(path):
+                os.makedirs(cache, exist_ok=True)
+                with open(path, "w") as f:
+                    f.write(self.get_tuning())
 
     def __call__(self, images):
         x = _h.to_dev(images)
@@ -118,6 +133,13 @@ class SSDModel(object):
             outs[0].append(d.cpu().numpy())
             outs[1].append(p.cpu().numpy())
         return np.concatenate(outs[0], 0), np.concatenate(outs[1], 0)
+
+    def get_tuning(self):
+        lib = _h.lib()
+        n = lib.ssd_net_get_tuning(self._net, None, 0)
+        buf = ctypes.create_string_buffer(n + 1)
+        lib.ssd_net_get_tuning(self._net, buf, n + 1)
+        return buf.value.decode()
 
     def fetch_activation(self, name):
         """Activation of a named layer of the last forward (debug / parity tests)."""

@@ -1,0 +1,66 @@
+"""Multi-GPU plumbing for the inference path: one process per GPU, contiguous batch shards,
+no collective in the data path.  ``torch.distributed`` (backend "nccl" == RCCL
+on ROCm; "gloo" on CPU in the tests) is used only to gather the fixed-size results and for
+timing barriers."""
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def env_rank():
+    return int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+
+
+def init_distributed(backend=None):
+    """Initialise the default process group from the torchrun environment (no-op for world 1)."""
+    rank, local_rank, world = env_rank()
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        kwargs = {}
+        if backend == "nccl":
+            torch.cuda.set_device(local_rank)
+            kwargs["device_id"] = torch.device("cuda", local_rank)
+        dist.init_process_group(backend, **kwargs)
+    return rank, local_rank, world
+
+
+def shard_range(n, rank, world):
+    """Contiguous shard [lo, hi) of n items for this rank; sizes differ by at most one."""
+    base, rem = divmod(n, world)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def gather_detections(boxes, labels, scores, n_total=None):
+    """All-gather per-rank detections ([b,T,4], [b,T], [b,T]) in rank order -> full batch on
+    every rank.  Shards may differ in size by one image (padded for the collective)."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return boxes, labels, scores
+    world = dist.get_world_size()
+    T = boxes.shape[1]
+    packed = torch.cat([boxes.reshape(boxes.shape[0], T * 4), labels, scores], dim=1)      # [b, 6T]
+    counts = [torch.zeros(1, dtype=torch.int64, device=packed.device) for _ in range(world)]
+    dist.all_gather(counts, torch.tensor([packed.shape[0]], dtype=torch.int64, device=packed.device))
+    counts = [int(c.item()) for c in counts]
+    mx = max(counts)
+    pad = torch.zeros((mx, 6 * T), dtype=packed.dtype, device=packed.device)
+    pad[:packed.shape[0]] = packed
+    parts = [torch.empty_like(pad) for _ in range(world)]
+    dist.all_gather(parts, pad)
+    full = torch.cat([p[:c] for p, c in zip(parts, counts)], dim=0)
+    if n_total is not None:
+        assert full.shape[0] == n_total
+    return full[:, :4 * T].reshape(-1, T, 4), full[:, 4 * T:5 * T], full[:, 5 * T:]
+
+
+def max_over_ranks(value):
+    """Max of a host float over all ranks (bench timing)."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return float(value)
+    dev = "cuda" if dist.get_backend() == "nccl" else "cpu"
+    t = torch.tensor([float(value)], dtype=torch.float64, device=dev)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())

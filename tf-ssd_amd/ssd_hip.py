@@ -69,6 +69,8 @@ _SIGNATURES = {
     "ssd_net_set_param": (ctypes.c_int, [vp, ctypes.c_char_p, c_float_p, ctypes.c_size_t]),
     "ssd_net_get_param": (ctypes.c_int, [vp, ctypes.c_char_p, c_float_p, ctypes.c_size_t]),
     "ssd_net_finalize": (ctypes.c_int, [vp, ctypes.c_int]),
+    "ssd_net_get_tuning": (ctypes.c_long, [vp, ctypes.c_char_p, ctypes.c_size_t]),
+    "ssd_net_set_tuning": (ctypes.c_int, [vp, ctypes.c_char_p]),
     "ssd_net_num_priors": (ctypes.c_int, [vp]),
     "ssd_net_feature_map_size": (ctypes.c_int, [vp, ctypes.c_int]),
     "ssd_net_forward": (ctypes.c_int, [vp, vp, ctypes.c_int, vp, vp, vp]),
