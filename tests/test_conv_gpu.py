@@ -274,3 +274,42 @@ def test_vgg16_ssd_forward_parity():
     assert _np(d).shape == (1, 8732, 4)
     assert np.abs(_np(p) - rp).max() <= 1e-4
     _close(_np(d), rd)
+
+
+def test_entry_point_scripts(tmp_path, monkeypatch, capsys):
+    """predictor.py / trainer.py keep the reference's flags and run end to end (E1)."""
+    import importlib
+    monkeypatch.chdir(tmp_path)
+    monkeypatch.setenv("SSD_SYNTHETIC_ITEMS", "40")
+    monkeypatch.setenv("SSD_TRAINER_STEPS", "2")
+    predictor = importlib.import_module("predictor")
+    b, l, s = predictor.main(["--backbone", "mobilenet_v2"])
+    assert b.shape == (40, 200, 4) and l.shape == (40, 200) and s.shape == (40, 200)
+    assert ((l > 0).sum(-1) > 0).all() and b.min() >= 0 and b.max() <= 1
+    trainer = importlib.import_module("trainer")
+    trainer.main(["--backbone", "mobilenet_v2", "-handle-gpu"])
+    out = capsys.readouterr().out
+    assert "loc_loss" in out and "step 1" in out
+
+
+def test_eval_utils_map():
+    """VOC07 11-point mAP (N2): perfect predictions -> AP 1; shuffled labels -> lower."""
+    from utils import eval_utils
+    labels = ["bg", "a", "b", "c"]
+    gt, gl = helpers.gt_inputs(6, G=5, L=4, seed=9)
+    T = 8
+    pb = np.zeros((6, T, 4), np.float32); pl = np.zeros((6, T), np.float32); ps = np.zeros((6, T), np.float32)
+    for i in range(6):
+        n = int((gl[i] > 0).sum())
+        pb[i, :n] = gt[i, :n]; pl[i, :n] = gl[i, :n]; ps[i, :n] = np.linspace(0.9, 0.6, n)
+    stats = eval_utils.init_stats(labels)
+    stats = eval_utils.update_stats(pb, pl, ps, gt, gl, stats)
+    stats, m = eval_utils.calculate_mAP(stats)
+    with_gt = [k for k in stats if stats[k]["total"] > 0]
+    assert with_gt and all(abs(stats[k]["AP"] - 1.0) < 1e-9 for k in with_gt)
+    # a class without GT/predictions contributes AP 0 to the mean, like the reference's loop
+    assert abs(float(m) - len(with_gt) / 3.0) < 1e-9
+    pl2 = pl.copy(); pl2[pl2 > 0] = (pl2[pl2 > 0] % 3) + 1
+    stats = eval_utils.update_stats(pb, pl2, ps, gt, gl, eval_utils.init_stats(labels))
+    _, m2 = eval_utils.calculate_mAP(stats)
+    assert float(m2) < float(m)
