@@ -223,6 +223,13 @@ const char* ssd_net_layer_kind(const ssd_net* net, int i);   /* "conv","dw","poo
 const char* ssd_net_layer_config(const ssd_net* net, int i); /* autotuned conv tile config */
 double ssd_net_layer_flops(const ssd_net* net, int i, int B); /* 2*MACs                  */
 double ssd_net_layer_bytes(const ssd_net* net, int i, int B); /* in + out + weights      */
+/* Options: "fuse_blocks" (default 1) runs eligible MobileNetV2 inverted-residual blocks
+ * (expand -> depthwise -> project) as one fused kernel; 0 runs them as three layers (then
+ * every intermediate activation is inspectable). */
+int ssd_net_set_option(ssd_net* net, const char* name, int value);
+/* Diagnostics: per-phase mean cycles per wave of one fused block layer (clock64 inside the
+ * kernel): prologue, expand, depthwise, project, weight staging, epilogue. */
+int ssd_net_profile_fused(ssd_net* net, const char* layer, int B, double* cycles_out6);
 /* Live per-layer hipEvent timing of ssd_net_forward / ssd_net_predict on their stream.
  * read_timing sums the durations (ms) of the forwards recorded since the last read into
  * ms_sum_out[num_layers + 1] (last entry: decode+NMS of predict) and reports their count. */

@@ -222,10 +222,22 @@ def test_mobilenet_v2_ssd_forward_parity(mbv2):
     x = helpers.images(2, 300, seed=0)
     acts = {}
     rd, rp = no.forward("mobilenet_v2", hp, w, x, acts)
+    # un-fused graph: every intermediate activation is inspectable
+    m.set_option("fuse_blocks", 0)
+    d0, p0 = m(x)
+    for name in ("Conv1_relu", "expanded_conv_project_BN", "block_1_expand_relu", "block_1_depthwise_relu",
+                 "block_3_out", "block_13_expand_relu", "out_relu", "extra1_2", "extra4_2"):
+        a = m.fetch_activation(name).reshape(acts[name].shape)
+        _close(a, acts[name])
+    assert np.abs(_np(p0) - rp).max() <= 1e-4
+    _close(_np(d0), rd)
+    # fused inverted-residual blocks (default): block outputs + final outputs
+    m.set_option("fuse_blocks", 1)
     d, p = m(x)
     d, p = _np(d), _np(p)
-    for name in ("Conv1_relu", "expanded_conv_project_BN", "block_1_depthwise_relu", "block_3_out",
-                 "block_13_expand_relu", "out_relu", "extra1_2", "extra4_2"):
+    assert any(l["kind"] == "fused" and l["flops"] > 0 for l in m.layers(2))
+    for name in ("block_1_out", "block_2_out", "block_3_out", "block_5_out", "block_6_out", "block_12_out",
+                 "block_13_expand_relu", "out_relu", "extra4_2"):
         a = m.fetch_activation(name).reshape(acts[name].shape)
         _close(a, acts[name])
     assert d.shape == (2, 2268, 4) and p.shape == (2, 2268, 21)

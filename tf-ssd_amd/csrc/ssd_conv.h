@@ -31,6 +31,25 @@ struct ConvParams {
     float* partial;
 };
 
+// One fused MobileNetV2 inverted-residual block (csrc/ssd_fused.hip).
+struct FusedBlockParams {
+    const float* x;
+    float* y;
+    const float* we;            // expand weights, packed [Ce][kpad_e]
+    const float *es, *eh;       // folded expand BN [Ce]
+    const float* wd;            // depthwise weights [9][Ce]
+    const float *ds, *dh;       // folded depthwise BN [Ce]
+    const float* wp;            // project weights, packed [npad_p][kpad_p]
+    const float *ps, *ph;       // folded project BN [Cout]
+    int residual;               // y += x (stride 1, Cin == Cout)
+    int B, H, W, Cin, Ce, Cout, Ho, Wo, stride, pad_t, pad_l;
+    int kpad_e, kpad_p, npad_p;
+    int tiles_y, tiles_x;       // filled by the launcher
+    long long* dbg;             // optional per-phase cycle counters [blocks][8] (profiling builds)
+};
+bool fused_block_supported(const FusedBlockParams& p);
+int launch_fused_block(FusedBlockParams p, hipStream_t st);
+
 inline int round_up(int v, int a) { return (v + a - 1) / a * a; }
 inline int conv_kpad(int K) { return round_up(K, 32); }
 inline int conv_npad(int Cout) { return round_up(Cout, 16); }

@@ -16,8 +16,8 @@
 
 namespace ssd {
 
-enum LayerKind { LK_CONV = 0, LK_DW, LK_POOL, LK_L2NORM, LK_SOFTMAX };
-static const char* kKindName[] = {"conv", "dw", "pool", "l2norm", "softmax"};
+enum LayerKind { LK_CONV = 0, LK_DW, LK_POOL, LK_L2NORM, LK_SOFTMAX, LK_FUSED };
+static const char* kKindName[] = {"conv", "dw", "pool", "l2norm", "softmax", "fused"};
 
 struct Param {
     std::string name;
@@ -54,6 +54,10 @@ struct Layer {
     float* shift = nullptr;
     int cfg = -1;
     int split_k = 1;
+    // fused inverted-residual block: LK_FUSED layer points at its three member layers;
+    // members carry the index of their LK_FUSED layer in `fused_by`
+    int f_expand = -1, f_dw = -1, f_project = -1;
+    int fused_by = -1;
 };
 
 }  // namespace ssd
@@ -72,6 +76,7 @@ struct ssd_net {
     std::vector<long> level_off;    // prior offset per level
     int num_priors = 0;
     bool finalized = false;
+    bool fuse_blocks = true;        // run eligible inverted-residual blocks as one fused kernel
     int max_batch = 0;
     int last_batch = 0;
     std::vector<float*> owned;      // device allocations to free
@@ -276,6 +281,22 @@ static void build_mobilenet_v2(ssd_net& net) {
         const bool res = (cin == cout && s == 1);
         x = b.conv(p + "project", p + "out", x, cout, 1, 1, 1, 1, p + "project_BN", false, SSD_ACT_NONE,
                    res ? inp : -1);
+        if (k != 13) {      // block 13's expanded map is SSD feature map #1: it must reach HBM
+            const int n = (int)net.layers.size();
+            Layer f;
+            f.name = p + "fused";
+            f.kind = LK_FUSED;
+            f.f_expand = n - 3; f.f_dw = n - 2; f.f_project = n - 1;
+            f.in = inp; f.out = x;
+            const Layer& le = net.layers[n - 3];
+            const Layer& ld = net.layers[n - 2];
+            f.H = le.H; f.W = le.W; f.Cin = le.Cin; f.Ho = ld.Ho; f.Wo = ld.Wo; f.Cout = cout;
+            f.stride = s; f.pt = ld.pt; f.pl = ld.pl;
+            net.layers.insert(net.layers.end() - 3, f);       // fused layer runs first, members follow
+            const int fi = n - 3;
+            net.layers[fi].f_expand = fi + 1; net.layers[fi].f_dw = fi + 2; net.layers[fi].f_project = fi + 3;
+            for (int j = 1; j <= 3; ++j) net.layers[fi + j].fused_by = fi;
+        }
         cin = cout;
     }
     x = b.conv("Conv_1", "out_relu", x, 1280, 1, 1, 1, 1, "Conv_1_bn", false, SSD_ACT_RELU6);
@@ -365,6 +386,25 @@ static ConvParams layer_conv_params(const ssd_net& net, const Layer& l, int B, c
     return p;
 }
 
+static FusedBlockParams fused_params(const ssd_net& net, const Layer& f, int B) {
+    const Layer& le = net.layers[f.f_expand];
+    const Layer& ld = net.layers[f.f_dw];
+    const Layer& lp = net.layers[f.f_project];
+    FusedBlockParams p{};
+    p.x = net.tensors[f.in].dev;
+    p.y = net.tensors[f.out].dev;
+    p.we = le.packed; p.es = le.scale; p.eh = le.shift;
+    p.wd = net.params[ld.p_kernel].dev; p.ds = ld.scale; p.dh = ld.shift;
+    p.wp = lp.packed; p.ps = lp.scale; p.ph = lp.shift;
+    p.residual = lp.res >= 0 ? 1 : 0;
+    p.B = B; p.H = f.H; p.W = f.W; p.Cin = f.Cin; p.Ce = le.Cout; p.Cout = f.Cout;
+    p.Ho = f.Ho; p.Wo = f.Wo; p.stride = f.stride; p.pad_t = f.pt; p.pad_l = f.pl;
+    p.kpad_e = conv_kpad(le.Cin);
+    p.kpad_p = conv_kpad(lp.Cin);
+    p.npad_p = conv_npad(lp.Cout);
+    return p;
+}
+
 static int run_layer(ssd_net& net, const Layer& l, int B, float* deltas_out, float* probs_out, hipStream_t st,
                      int cfg_override = -1) {
     const float* in = l.in >= 0 ? net.tensors[l.in].dev : nullptr;
@@ -384,8 +424,21 @@ static int run_layer(ssd_net& net, const Layer& l, int B, float* deltas_out, flo
             return launch_l2norm(in, (long)B * l.H * l.W, l.Cin, net.params[l.p_gamma].dev, out, st);
         case LK_SOFTMAX:
             return launch_softmax(probs_out, (long)B * net.num_priors, net.L, probs_out, st);
+        case LK_FUSED:
+            return launch_fused_block(fused_params(net, l, B), st);
     }
     return SSD_OK;
+}
+
+// A fused layer is active when fusion is on and the kernel supports its shape; then its
+// three member layers are skipped (and vice versa).
+static bool fused_active(const ssd_net& net, const Layer& f) {
+    return net.fuse_blocks && fused_block_supported(fused_params(net, f, 1));
+}
+static bool layer_runs(const ssd_net& net, const Layer& l) {
+    if (l.kind == LK_FUSED) return fused_active(net, l);
+    if (l.fused_by >= 0) return !fused_active(net, net.layers[l.fused_by]);
+    return true;
 }
 
 static int dev_alloc(ssd_net& net, size_t floats, float** out) {
@@ -697,8 +750,10 @@ static int forward_impl(ssd_net* net, const float* image_dev, int B, float* delt
         (void)hipEventRecord((*ev)[0], st);
     }
     for (size_t i = 0; i < net->layers.size(); ++i) {
-        const int rc = run_layer(*net, net->layers[i], B, deltas_out, probs_out, st);
-        if (rc) return rc;
+        if (layer_runs(*net, net->layers[i])) {
+            const int rc = run_layer(*net, net->layers[i], B, deltas_out, probs_out, st);
+            if (rc) return rc;
+        }
         if (ev) (void)hipEventRecord((*ev)[i + 1], st);
     }
     net->last_batch = B;
@@ -738,6 +793,51 @@ int ssd_net_predict(ssd_net* net, const float* image_dev, int B, const float* pr
     if (!rc && net->timing && !net->timing_events.empty())
         (void)hipEventRecord(net->timing_events.back().back(), (hipStream_t)stream);
     return rc;
+}
+
+// Diagnostics: run one fused block layer with the kernel's per-phase clock64() counters on
+// and return, per phase, the mean cycles per wave (6 phases: prologue, expand, depthwise,
+// project, weight stage, epilogue).  Requires a previous forward at batch >= B.
+int ssd_net_profile_fused(ssd_net* net, const char* layer, int B, double* cycles_out6) {
+    SSD_CHECK_ARG(net && layer && cycles_out6 && B >= 1, "ssd_net_profile_fused: bad arguments");
+    if (!net->finalized) { set_error("ssd_net_profile_fused: not finalized"); return SSD_E_STATE; }
+    const Layer* f = nullptr;
+    for (const auto& l : net->layers)
+        if (l.kind == LK_FUSED && l.name == layer) f = &l;
+    SSD_CHECK_ARG(f != nullptr, "ssd_net_profile_fused: unknown fused layer '%s'", layer);
+    FusedBlockParams p = fused_params(*net, *f, B);
+    SSD_CHECK_ARG(fused_block_supported(p), "ssd_net_profile_fused: layer not supported by the fused kernel");
+    const size_t n = (size_t)B * 4096 * 4 * 6;     // upper bound: <= 4096 tiles per image
+    long long* d = nullptr;
+    SSD_HIP(hipMalloc((void**)&d, n * sizeof(long long)));
+    SSD_HIP(hipMemset(d, 0, n * sizeof(long long)));
+    p.dbg = d;
+    int rc = launch_fused_block(p, nullptr);
+    if (!rc && hipDeviceSynchronize() != hipSuccess) rc = SSD_E_HIP;
+    if (!rc) {
+        std::vector<long long> h(n);
+        SSD_HIP(hipMemcpy(h.data(), d, n * sizeof(long long), hipMemcpyDeviceToHost));
+        double sum[6] = {0, 0, 0, 0, 0, 0};
+        size_t waves = 0;
+        for (size_t w = 0; w + 5 < n; w += 6) {
+            if (h[w] == 0 && h[w + 5] == 0) continue;
+            for (int i = 0; i < 6; ++i) sum[i] += (double)h[w + i];
+            ++waves;
+        }
+        for (int i = 0; i < 6; ++i) cycles_out6[i] = waves ? sum[i] / waves : 0;
+    }
+    (void)hipFree(d);
+    return rc;
+}
+
+int ssd_net_set_option(ssd_net* net, const char* name, int value) {
+    SSD_CHECK_ARG(net && name, "ssd_net_set_option: NULL argument");
+    if (std::string(name) == "fuse_blocks") {
+        net->fuse_blocks = value != 0;
+        return SSD_OK;
+    }
+    set_error("ssd_net_set_option: unknown option '%s'", name);
+    return SSD_E_INVALID;
 }
 
 int ssd_net_set_timing(ssd_net* net, int enabled) {
@@ -807,6 +907,15 @@ const char* ssd_net_layer_config(const ssd_net* net, int i) {
 double ssd_net_layer_flops(const ssd_net* net, int i, int B) {
     if (!net || i < 0 || i >= (int)net->layers.size()) return 0;
     const Layer& l = net->layers[i];
+    if (!layer_runs(*net, l)) return 0;
+    if (l.kind == LK_FUSED) {
+        double f = 0;
+        const_cast<ssd_net*>(net)->fuse_blocks = false;     // member flops (algorithmic, no halo recompute)
+        f = ssd_net_layer_flops(net, l.f_expand, B) + ssd_net_layer_flops(net, l.f_dw, B) +
+            ssd_net_layer_flops(net, l.f_project, B);
+        const_cast<ssd_net*>(net)->fuse_blocks = true;
+        return f;
+    }
     const double px = (double)B * l.Ho * l.Wo;
     if (l.kind == LK_CONV) return 2.0 * px * l.kh * l.kw * l.Cin * l.Cout;
     if (l.kind == LK_DW) return 2.0 * px * 9 * l.Cout;
@@ -815,6 +924,9 @@ double ssd_net_layer_flops(const ssd_net* net, int i, int B) {
 double ssd_net_layer_bytes(const ssd_net* net, int i, int B) {
     if (!net || i < 0 || i >= (int)net->layers.size()) return 0;
     const Layer& l = net->layers[i];
+    if (!layer_runs(*net, l)) return 0;
+    if (l.kind == LK_FUSED)
+        return 4.0 * B * ((double)l.H * l.W * l.Cin + (double)l.Ho * l.Wo * l.Cout);
     if (l.kind == LK_SOFTMAX) return 2.0 * 4.0 * B * net->num_priors * net->L;
     double b = 4.0 * B * ((double)l.H * l.W * l.Cin + (double)l.Ho * l.Wo * l.Cout);
     if (l.res >= 0) b += 4.0 * B * (double)l.Ho * l.Wo * l.Cout;
@@ -841,7 +953,8 @@ int ssd_net_profile_layers(ssd_net* net, const float* image_dev, int B, int reps
     (void)hipEventCreate(&e1);
     for (size_t i = 0; i < net->layers.size() && !rc; ++i) {
         (void)hipEventRecord(e0, st);
-        for (int r = 0; r < reps && !rc; ++r) rc = run_layer(*net, net->layers[i], B, d, pr, st);
+        for (int r = 0; r < reps && !rc && layer_runs(*net, net->layers[i]); ++r)
+            rc = run_layer(*net, net->layers[i], B, d, pr, st);
         (void)hipEventRecord(e1, st);
         (void)hipEventSynchronize(e1);
         float ms = 0.f;

@@ -186,6 +186,9 @@ class SSDModel(object):
         self._last_input = x
         return boxes, labels, scores, valid
 
+    def set_option(self, name, value):
+        _h.check(_h.lib().ssd_net_set_option(self._net, name.encode(), int(value)), "set_option")
+
     def set_timing(self, enabled):
         _h.check(_h.lib().ssd_net_set_timing(self._net, int(enabled)), "set_timing")
 

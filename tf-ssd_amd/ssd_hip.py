@@ -83,6 +83,8 @@ _SIGNATURES = {
     "ssd_net_layer_config": (ctypes.c_char_p, [vp, ctypes.c_int]),
     "ssd_net_layer_flops": (ctypes.c_double, [vp, ctypes.c_int, ctypes.c_int]),
     "ssd_net_layer_bytes": (ctypes.c_double, [vp, ctypes.c_int, ctypes.c_int]),
+    "ssd_net_set_option": (ctypes.c_int, [vp, ctypes.c_char_p, ctypes.c_int]),
+    "ssd_net_profile_fused": (ctypes.c_int, [vp, ctypes.c_char_p, ctypes.c_int, ctypes.POINTER(ctypes.c_double)]),
     "ssd_net_set_timing": (ctypes.c_int, [vp, ctypes.c_int]),
     "ssd_net_read_timing": (ctypes.c_int, [vp, c_float_p, c_int_p]),
     "ssd_net_profile_layers": (ctypes.c_int, [vp, vp, ctypes.c_int, ctypes.c_int, c_float_p, vp]),
