@@ -223,7 +223,9 @@ const char* ssd_net_layer_kind(const ssd_net* net, int i);   /* "conv","dw","poo
 const char* ssd_net_layer_config(const ssd_net* net, int i); /* autotuned conv tile config */
 double ssd_net_layer_flops(const ssd_net* net, int i, int B); /* 2*MACs                  */
 double ssd_net_layer_bytes(const ssd_net* net, int i, int B); /* in + out + weights      */
-/* Options: "fuse_blocks" (default 1) runs eligible MobileNetV2 inverted-residual blocks
+/* Options: "use_graph" (default 1) replays each forward/predict step as one captured hipGraph
+ * (keyed by the pointers/sizes of the call; streams other than the NULL stream only);
+ * "fuse_blocks" (default 1) runs eligible MobileNetV2 inverted-residual blocks
  * (expand -> depthwise -> project) as one fused kernel; 0 runs them as three layers (then
  * every intermediate activation is inspectable). */
 int ssd_net_set_option(ssd_net* net, const char* name, int value);

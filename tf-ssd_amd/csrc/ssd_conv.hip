@@ -39,9 +39,8 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvParams p) {
     constexpr int XU = BM * UPR, WU = BN * UPR;
     constexpr int XP = (XU + 255) / 256, WP = (WU + 255) / 256;
     static_assert(WM * WN == 4, "4 waves per block");
-    __shared__ __attribute__((aligned(16))) float smem[(BM + BN) * LDK];
-    float* Xs = smem;
-    float* Ws = smem + BM * LDK;
+    // two LDS stages: tile kt+1 is written while tile kt is multiplied -> one barrier per K tile
+    __shared__ __attribute__((aligned(16))) float smem[2 * (BM + BN) * LDK];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
@@ -115,7 +114,9 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvParams p) {
                 wr[ps] = *reinterpret_cast<const f32x4*>(p.w + (long)n * p.Kpad + k0 + kq4);
         }
     };
-    auto store_tile = [&]() {
+    auto store_tile = [&](int stage) {
+        float* Xs = smem + stage * (BM + BN) * LDK;
+        float* Ws = Xs + BM * LDK;
 #pragma unroll
         for (int ps = 0; ps < XP; ++ps) {
             const int u = tid + ps * 256;
@@ -135,10 +136,15 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvParams p) {
         for (int ni = 0; ni < NT; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     const int frow = lane & 15, fk = (lane >> 4) * 4;
-    if (kt_begin < kt_end) load_tile(kt_begin);
+    if (kt_begin < kt_end) {
+        load_tile(kt_begin);
+        store_tile(0);
+    }
+    __syncthreads();
     for (int kt = kt_begin; kt < kt_end; ++kt) {
-        store_tile();
-        __syncthreads();
+        const int stage = (kt - kt_begin) & 1;
+        const float* Xs = smem + stage * (BM + BN) * LDK;
+        const float* Ws = Xs + BM * LDK;
         if (kt + 1 < kt_end) load_tile(kt + 1);
 #pragma unroll
         for (int kc = 0; kc < BK / 16; ++kc) {
@@ -157,6 +163,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvParams p) {
                     for (int ni = 0; ni < NT; ++ni)
                         acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[ni][s], b[mi][s], acc[mi][ni], 0, 0, 0);
         }
+        if (kt + 1 < kt_end) store_tile(stage ^ 1);
         __syncthreads();
     }
 
@@ -439,6 +446,14 @@ static const ConvCfg kCfgs[] = {
     CFG(1, 5, 2, 2, 32),   // 19: 32 x 160
     CFG(4, 3, 2, 2, 32),   // 20: 128 x 96 (64 x 48 wave tiles)
     CFG(4, 6, 2, 2, 32),   // 21: 128 x 192
+    CFG(1, 7, 4, 1, 64),   // 22..: BK = 64 variants for the long-K 3x3 convs (heads, extras)
+    CFG(1, 5, 2, 2, 64),
+    CFG(2, 7, 4, 1, 64),
+    CFG(2, 5, 2, 2, 64),
+    CFG(1, 2, 2, 2, 64),
+    CFG(2, 4, 2, 2, 64),
+    CFG(1, 1, 4, 1, 64),
+    CFG(2, 2, 2, 2, 64),
 };
 constexpr int kNumMfmaCfgs = sizeof(kCfgs) / sizeof(kCfgs[0]);
 constexpr int kDirectCfg = kNumMfmaCfgs;       // last config id = VALU direct kernel

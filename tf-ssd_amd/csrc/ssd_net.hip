@@ -58,6 +58,9 @@ struct Layer {
     // members carry the index of their LK_FUSED layer in `fused_by`
     int f_expand = -1, f_dw = -1, f_project = -1;
     int fused_by = -1;
+    float* splitk_part = nullptr;   // this layer's own split-K slab (layers may run concurrently)
+    int side = 0;                   // 1: runs on the side stream (SSD head convs)
+    hipEvent_t ev_ready = nullptr;  // recorded on the main stream when this layer's OUTPUT is complete
 };
 
 }  // namespace ssd
@@ -90,6 +93,24 @@ struct ssd_net {
     size_t nms_ws_bytes = 0;
     // optional per-layer hipEvent timing of forward()/predict() (bench.py roofline leg)
     std::map<std::string, std::pair<std::string, int>> preset;   // layer -> (config name, split_k)
+    // hipGraph replay of a whole forward/predict step, keyed by every pointer baked into it
+    bool use_graph = true;
+    struct GraphEntry {
+        std::vector<const void*> key;
+        hipGraphExec_t exec = nullptr;
+        hipGraph_t graph = nullptr;
+    };
+    std::vector<GraphEntry> graphs;
+    // graphs cannot be captured on the legacy NULL stream (PyTorch's default stream): such
+    // calls are captured/replayed on this BLOCKING stream, which the NULL stream implicitly
+    // orders with (legacy default-stream semantics), so callers see the same ordering.
+    hipStream_t gstream = nullptr;
+    // the head convs only depend on their feature map: they run on `side` concurrently with the
+    // rest of the backbone / extras (fork after the producer, join before the softmax)
+    bool overlap_heads = true;
+    hipStream_t side = nullptr;
+    hipEvent_t ev_side_done = nullptr;
+    float* splitk_layers = nullptr;     // per-layer split-K slabs (post-autotune)
     bool timing = false;
     std::vector<std::vector<hipEvent_t>> timing_events;   // one vector of (layers + 2) events per forward
 
@@ -105,6 +126,20 @@ struct ssd_net {
         if (nms_ws) (void)hipFree(nms_ws);
         for (auto& v : timing_events)
             for (auto e : v) (void)hipEventDestroy(e);
+        drop_graphs();
+        if (gstream) (void)hipStreamDestroy(gstream);
+        if (side) (void)hipStreamDestroy(side);
+        if (ev_side_done) (void)hipEventDestroy(ev_side_done);
+        for (auto& l : layers)
+            if (l.ev_ready) (void)hipEventDestroy(l.ev_ready);
+        if (splitk_layers) (void)hipFree(splitk_layers);
+    }
+    void drop_graphs() {
+        for (auto& g : graphs) {
+            if (g.exec) (void)hipGraphExecDestroy(g.exec);
+            if (g.graph) (void)hipGraphDestroy(g.graph);
+        }
+        graphs.clear();
     }
 };
 
@@ -249,6 +284,7 @@ struct Builder {
             l.head2_off = net.level_off[i] * 4;
             l.head2_bs = (long)net.num_priors * 4;
             l.head2_ps = (long)A * 4;
+            l.side = 1;
             net.layers.push_back(l);
         }
         Layer sm;
@@ -367,7 +403,7 @@ static ConvParams layer_conv_params(const ssd_net& net, const Layer& l, int B, c
     p.M = (long)B * l.Ho * l.Wo;
     p.act = l.act;
     p.split_k = l.split_k;
-    p.partial = net.splitk_ws;
+    p.partial = l.splitk_part ? l.splitk_part : net.splitk_ws;
     if (l.head_kind == 0) {
         p.out = out;
         p.out_pixel_stride = l.Cout;
@@ -525,6 +561,56 @@ static int autotune(ssd_net& net, int B, hipStream_t st) {
 
 }  // namespace ssd
 
+// Capture `body` (a sequence of launches on st) into a hipGraph the first time a key is seen
+// and replay it afterwards: one host call per step instead of ~70 launches.
+template <typename F>
+static int run_graphed(ssd_net* net, std::vector<const void*> key, hipStream_t& st, F body) {
+    if (!net->use_graph || net->timing) return body();
+    const hipStream_t caller = st;
+    if (st == nullptr) {
+        if (!net->gstream && hipStreamCreateWithFlags(&net->gstream, hipStreamDefault) != hipSuccess) {
+            (void)hipGetLastError();
+            return body();
+        }
+        st = net->gstream;
+    }
+    key.push_back((const void*)st);
+    for (auto& g : net->graphs)
+        if (g.key == key) {
+            SSD_HIP(hipGraphLaunch(g.exec, st));
+            return SSD_OK;
+        }
+    if (net->graphs.size() >= 16) net->drop_graphs();
+    // first sight of this key: run eagerly once on the caller's stream (validates arguments,
+    // sets kernel attributes), then capture the same launches
+    st = caller;
+    int rc = body();
+    if (rc) return rc;
+    st = caller ? caller : net->gstream;
+    ssd_net::GraphEntry e;
+    e.key = std::move(key);
+    if (hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal) != hipSuccess) {
+        (void)hipGetLastError();
+        return SSD_OK;               // capture unavailable: stay eager
+    }
+    rc = body();
+    const hipError_t ce = hipStreamEndCapture(st, &e.graph);
+    if (rc || ce != hipSuccess || !e.graph) {
+        (void)hipGetLastError();
+        if (e.graph) (void)hipGraphDestroy(e.graph);
+        net->use_graph = false;      // fall back to eager launches for this net
+        return rc ? rc : SSD_OK;
+    }
+    if (hipGraphInstantiate(&e.exec, e.graph, nullptr, nullptr, 0) != hipSuccess) {
+        (void)hipGetLastError();
+        (void)hipGraphDestroy(e.graph);
+        net->use_graph = false;
+        return SSD_OK;
+    }
+    net->graphs.push_back(e);
+    return SSD_OK;
+}
+
 extern "C" {
 
 ssd_net* ssd_net_create(int backbone, int img_size, int levels, const int* n_ars, int total_labels) {
@@ -573,6 +659,7 @@ int ssd_net_set_param(ssd_net* net, const char* name, const float* host_data, si
     SSD_HIP(hipMemcpy(p.dev, host_data, p.count * sizeof(float), hipMemcpyHostToDevice));
     p.set = true;
     net->finalized = false;
+    net->drop_graphs();
     return SSD_OK;
 }
 
@@ -602,8 +689,11 @@ int ssd_net_finalize(ssd_net* net, int max_batch) {
     for (float* p : net->owned)
         if (p) (void)hipFree(p);
     net->owned.clear();
+    if (net->splitk_layers) (void)hipFree(net->splitk_layers);
+    net->splitk_layers = nullptr;
     for (auto& l : net->layers) {
         l.packed = l.scale = l.shift = nullptr;
+        l.splitk_part = nullptr;        // autotune runs on the shared slab; per-layer slabs are re-planned below
         if (l.kind == LK_CONV) {
             const int K = l.kh * l.kw * l.Cin;
             int rc = dev_alloc(*net, (size_t)conv_kpad(K) * conv_npad(l.Cout), &l.packed);
@@ -688,7 +778,32 @@ int ssd_net_finalize(ssd_net* net, int max_batch) {
         rc = autotune(*net, max_batch, st);
     }
     if (rc) return rc;
+    // every split-K layer gets its own slab (layers on different streams may overlap)
+    {
+        if (net->splitk_layers) (void)hipFree(net->splitk_layers);
+        net->splitk_layers = nullptr;
+        size_t total_ws = 0;
+        for (auto& l : net->layers) {
+            l.splitk_part = nullptr;
+            if (l.kind == LK_CONV && l.split_k > 1)
+                total_ws += align_up((size_t)l.split_k * max_batch * l.Ho * l.Wo * l.Cout, 64);
+        }
+        if (total_ws) {
+            SSD_HIP(hipMalloc((void**)&net->splitk_layers, total_ws * sizeof(float)));
+            size_t o = 0;
+            for (auto& l : net->layers)
+                if (l.kind == LK_CONV && l.split_k > 1) {
+                    l.splitk_part = net->splitk_layers + o;
+                    o += align_up((size_t)l.split_k * max_batch * l.Ho * l.Wo * l.Cout, 64);
+                }
+        }
+        if (!net->side) SSD_HIP(hipStreamCreateWithFlags(&net->side, hipStreamNonBlocking));
+        if (!net->ev_side_done) SSD_HIP(hipEventCreateWithFlags(&net->ev_side_done, hipEventDisableTiming));
+        for (auto& l : net->layers)
+            if (!l.ev_ready) SSD_HIP(hipEventCreateWithFlags(&l.ev_ready, hipEventDisableTiming));
+    }
     SSD_HIP(hipDeviceSynchronize());
+    net->drop_graphs();
     net->finalized = true;
     return SSD_OK;
 }
@@ -749,12 +864,47 @@ static int forward_impl(ssd_net* net, const float* image_dev, int B, float* delt
         for (auto& e : *ev) SSD_HIP(hipEventCreate(&e));
         (void)hipEventRecord((*ev)[0], st);
     }
+    const bool overlap = net->overlap_heads && !net->timing && net->side;
+    // which layers feed a side-stream layer (their completion must be published)
+    bool side_used = false;
     for (size_t i = 0; i < net->layers.size(); ++i) {
-        if (layer_runs(*net, net->layers[i])) {
-            const int rc = run_layer(*net, net->layers[i], B, deltas_out, probs_out, st);
-            if (rc) return rc;
+        Layer& l = net->layers[i];
+        if (layer_runs(*net, l)) {
+            if (overlap && l.side) {
+                // fork: the producer of this layer's input recorded ev_ready on the main stream
+                int prod = -1;
+                for (int j = (int)i - 1; j >= 0; --j)
+                    if (net->layers[j].out == l.in && layer_runs(*net, net->layers[j])) { prod = j; break; }
+                if (prod >= 0) SSD_HIP(hipStreamWaitEvent(net->side, net->layers[prod].ev_ready, 0));
+                else {      // input produced before any layer (the image): order after current main work
+                    SSD_HIP(hipEventRecord(l.ev_ready, st));
+                    SSD_HIP(hipStreamWaitEvent(net->side, l.ev_ready, 0));
+                }
+                const int rc = run_layer(*net, l, B, deltas_out, probs_out, net->side);
+                if (rc) return rc;
+                side_used = true;
+            } else {
+                if (l.kind == LK_SOFTMAX && side_used) {        // join before the softmax
+                    SSD_HIP(hipEventRecord(net->ev_side_done, net->side));
+                    SSD_HIP(hipStreamWaitEvent(st, net->ev_side_done, 0));
+                    side_used = false;
+                }
+                const int rc = run_layer(*net, l, B, deltas_out, probs_out, st);
+                if (rc) return rc;
+                if (overlap) {
+                    // publish completion if some later side layer consumes this output
+                    bool feeds_side = false;
+                    for (size_t j = i + 1; j < net->layers.size() && !feeds_side; ++j)
+                        feeds_side = net->layers[j].side && net->layers[j].in == l.out && l.out >= 0;
+                    if (feeds_side) SSD_HIP(hipEventRecord(l.ev_ready, st));
+                }
+            }
         }
         if (ev) (void)hipEventRecord((*ev)[i + 1], st);
+    }
+    if (side_used) {    // no softmax layer after the side work: still join
+        SSD_HIP(hipEventRecord(net->ev_side_done, net->side));
+        SSD_HIP(hipStreamWaitEvent(st, net->ev_side_done, 0));
     }
     net->last_batch = B;
     return SSD_OK;
@@ -762,7 +912,10 @@ static int forward_impl(ssd_net* net, const float* image_dev, int B, float* delt
 
 int ssd_net_forward(ssd_net* net, const float* image_dev, int B, float* deltas_out_dev, float* probs_out_dev,
                     void* stream) {
-    return forward_impl(net, image_dev, B, deltas_out_dev, probs_out_dev, (hipStream_t)stream);
+    SSD_CHECK_ARG(net != nullptr, "ssd_net_forward: net is NULL");
+    hipStream_t st = (hipStream_t)stream;
+    return run_graphed(net, {image_dev, deltas_out_dev, probs_out_dev, (const void*)(intptr_t)B, (const void*)1}, st,
+                       [&]() { return forward_impl(net, image_dev, B, deltas_out_dev, probs_out_dev, st); });
 }
 
 int ssd_net_predict(ssd_net* net, const float* image_dev, int B, const float* priors_dev, const float* var,
@@ -785,13 +938,24 @@ int ssd_net_predict(ssd_net* net, const float* image_dev, int B, const float* pr
         SSD_HIP(hipMalloc(&net->nms_ws, need));
         net->nms_ws_bytes = need;
     }
-    int rc = forward_impl(net, image_dev, B, net->deltas, net->probs, (hipStream_t)stream);
-    if (rc) return rc;
-    rc = ssd_decode_nms(net->deltas, net->probs, priors_dev, var, B, N, L, max_total, max_total, iou_thr,
-                        score_thr, boxes_dev, labels_dev, scores_dev, valid_dev, nullptr, net->nms_ws,
-                        net->nms_ws_bytes, stream);
+    hipStream_t st = (hipStream_t)stream;
+    SSD_CHECK_ARG(var != nullptr, "ssd_net_predict: variances pointer is NULL");
+    const float v4[4] = {var[0], var[1], var[2], var[3]};
+    union { float f; intptr_t i; } k1{}, k2{};
+    k1.f = iou_thr; k2.f = score_thr;
+    std::vector<const void*> key = {image_dev, priors_dev, boxes_dev, labels_dev, scores_dev, valid_dev,
+                                    (const void*)(intptr_t)B, (const void*)(intptr_t)max_total,
+                                    (const void*)k1.i, (const void*)k2.i, (const void*)2};
+    for (int i = 0; i < 4; ++i) { union { float f; intptr_t i; } k{}; k.f = v4[i]; key.push_back((const void*)k.i); }
+    int rc = run_graphed(net, key, st, [&]() {
+        int r = forward_impl(net, image_dev, B, net->deltas, net->probs, st);
+        if (r) return r;
+        return ssd_decode_nms(net->deltas, net->probs, priors_dev, v4, B, N, L, max_total, max_total, iou_thr,
+                              score_thr, boxes_dev, labels_dev, scores_dev, valid_dev, nullptr, net->nms_ws,
+                              net->nms_ws_bytes, (void*)st);
+    });
     if (!rc && net->timing && !net->timing_events.empty())
-        (void)hipEventRecord(net->timing_events.back().back(), (hipStream_t)stream);
+        (void)hipEventRecord(net->timing_events.back().back(), st);
     return rc;
 }
 
@@ -834,6 +998,17 @@ int ssd_net_set_option(ssd_net* net, const char* name, int value) {
     SSD_CHECK_ARG(net && name, "ssd_net_set_option: NULL argument");
     if (std::string(name) == "fuse_blocks") {
         net->fuse_blocks = value != 0;
+        net->drop_graphs();
+        return SSD_OK;
+    }
+    if (std::string(name) == "overlap_heads") {
+        net->overlap_heads = value != 0;
+        net->drop_graphs();
+        return SSD_OK;
+    }
+    if (std::string(name) == "use_graph") {
+        net->use_graph = value != 0;
+        net->drop_graphs();
         return SSD_OK;
     }
     set_error("ssd_net_set_option: unknown option '%s'", name);
