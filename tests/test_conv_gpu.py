@@ -236,7 +236,7 @@ def test_mobilenet_v2_ssd_forward_parity(mbv2):
     d, p = m(x)
     d, p = _np(d), _np(p)
     assert any(l["kind"] == "fused" and l["flops"] > 0 for l in m.layers(2))
-    for name in ("block_1_out", "block_2_out", "block_3_out", "block_5_out", "block_6_out", "block_12_out",
+    for name in ("expanded_conv_project_BN", "block_1_out", "block_2_out", "block_3_out", "block_5_out", "block_6_out", "block_12_out",
                  "block_13_expand_relu", "out_relu", "extra4_2"):
         a = m.fetch_activation(name).reshape(acts[name].shape)
         _close(a, acts[name])
@@ -325,3 +325,31 @@ def test_eval_utils_map():
     stats = eval_utils.update_stats(pb, pl2, ps, gt, gl, eval_utils.init_stats(labels))
     _, m2 = eval_utils.calculate_mAP(stats)
     assert float(m2) < float(m)
+
+
+@pytest.mark.parametrize("H,Cin,Cout,k,stride", [(19, 576, 100, 3, 1), (10, 1280, 150, 3, 1), (5, 512, 150, 3, 1),
+                                                 (10, 256, 512, 3, 2), (3, 256, 150, 3, 1), (1, 256, 100, 3, 1),
+                                                 (10, 1280, 256, 1, 1), (19, 96, 576, 1, 1)])
+def test_conv2d_every_config_and_split_on_net_shapes(H, Cin, Cout, k, stride):
+    """The autotuner may pick ANY valid (tile config, split-K) for a layer; every such choice
+    must be correct on the real SSD layer shapes (long K, ragged N, tiny M)."""
+    import ssd_hip as h
+    lib = h.lib()
+    rng = np.random.default_rng(H * Cin + Cout)
+    B = 2
+    x = rng.standard_normal((B, H, H, Cin)).astype(np.float32)
+    w = (rng.standard_normal((k, k, Cin, Cout)) / np.sqrt(k * k * Cin)).astype(np.float32)
+    bias = rng.uniform(-0.5, 0.5, Cout).astype(np.float32)
+    pads = same(H, k, stride) * 2 if k == 3 else (0, 0, 0, 0)
+    ref = no.relu(no.conv2d(x, w, bias, stride, 1, "same" if k == 3 else "valid"))
+    ran = 0
+    for cfg in range(lib.ssd_conv_num_configs()):
+        for split in (1, 2, 4, 8, 16):
+            rc, out = run_conv(x, w, None, bias, None, stride, 1, pads, act=1, cfg=cfg, split_k=split)
+            if rc == -3:
+                break
+            assert rc == 0, (cfg, split, lib.ssd_last_error())
+            err = float(np.abs(_np(out) - ref).max())
+            assert err <= 1e-4 * max(1.0, float(np.abs(ref).max())), (lib.ssd_conv_config_name(cfg), split, err)
+            ran += 1
+    assert ran >= 20

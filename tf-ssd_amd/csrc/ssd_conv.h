@@ -47,6 +47,21 @@ struct FusedBlockParams {
     int tiles_y, tiles_x;       // filled by the launcher
     long long* dbg;             // optional per-phase cycle counters [blocks][8] (profiling builds)
 };
+// Fused MobileNetV2 stem (Conv1 -> expanded_conv_depthwise -> expanded_conv_project).
+struct StemParams {
+    const float* x;             // image [B,H,W,3]
+    float* y;                   // [B,H1,W1,16]
+    const float* w1;            // Conv1 weights packed [32][kpad1]
+    const float *s1, *h1;       // folded Conv1 BN [32]
+    const float* wd;            // depthwise weights [9][32]
+    const float *sd, *hd;
+    const float* wp;            // project weights packed [16][kpadp]
+    const float *sp, *hp;       // folded project BN [16]
+    int B, H, W, H1, W1, pad_t, pad_l, kpad1, kpadp;
+    int tiles_y, tiles_x;
+};
+bool stem_supported(const StemParams& p);
+int launch_stem(StemParams p, hipStream_t st);
 bool fused_block_supported(const FusedBlockParams& p);
 int launch_fused_block(FusedBlockParams p, hipStream_t st);
 
@@ -74,6 +89,9 @@ int launch_maxpool(const float* in, int B, int H, int W, int C, int k, int strid
 int launch_l2norm(const float* in, long pixels, int C, const float* gamma, float* out, hipStream_t st);
 int launch_softmax(const float* in, long rows, int L, float* out, hipStream_t st);
 int launch_pack_weights(const float* hwio, int K, int Cout, int Kpad, int Npad, float* packed, hipStream_t st);
+// out[r][c] = in[r][c] * scale[r] (rows >= nvalid copied unscaled); out[r][c] = in[r][c] * scale[c]
+int launch_scale_rows(const float* in, const float* scale, int rows, int nvalid, int cols, float* out, hipStream_t st);
+int launch_scale_cols(const float* in, const float* scale, int rows, int cols, float* out, hipStream_t st);
 int launch_fold_bn(const float* gamma, const float* beta, const float* mean, const float* var, float eps,
                    int C, float* scale, float* shift, hipStream_t st);
 

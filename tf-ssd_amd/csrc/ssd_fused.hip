@@ -17,6 +17,8 @@
 // depthwise tensors never leave the CU; HBM traffic is x in + y out (+ weights from L2).
 // Halo pixels are expanded redundantly (100/64 for an 8x8 stride-1 tile).  Weight chunks are
 // prefetched global->registers one chunk ahead.
+#include <cstdlib>
+
 #include "ssd_conv.h"
 
 namespace ssd {
@@ -24,6 +26,34 @@ namespace ssd {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ float relu6f(float v) { return fminf(fmaxf(v, 0.0f), 6.0f); }
+
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() carries a workgroup fence
+// over ALL address spaces, and since vmcnt also counts stores on gfx950 the compiler then
+// drains every outstanding global load (s_waitcnt vmcnt(0)) at the first LDS access after
+// the barrier -- which would stall on the weight / next-tile prefetch that is deliberately
+// kept in flight across the phases of this kernel.
+__device__ __forceinline__ void lds_barrier() {
+    // (an address-space-restricted __builtin_amdgcn_fence(..., "local") still drained vmcnt on
+    // ROCm 7.2, hence the explicit LDS-counter wait + raw barrier; "memory" keeps the compiler
+    // from moving LDS accesses across it)
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
+// Prefetch loads the compiler must not wait for: a 16-byte global load issued through inline
+// asm is invisible to hipcc's s_waitcnt bookkeeping, so it stays in flight across the phase
+// barriers; wait_prefetch() is the matching hand-placed wait (every destination is passed
+// through an empty "+v" statement so no consumer can be scheduled above the wait).
+__device__ __forceinline__ f32x4 gload16_async(const float* ptr) {
+    f32x4 v;
+    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(v) : "v"(ptr) : "memory");
+    return v;
+}
+template <int N>
+__device__ __forceinline__ void wait_prefetch(f32x4 (&r)[N]) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int i = 0; i < N; ++i) asm volatile("" : "+v"(r[i]));
+}
 
 constexpr int kCK = 48;          // expanded channels per chunk
 constexpr int kLDE = kCK + 4;    // LDS row stride of E / D / Wp chunk tiles
@@ -38,11 +68,14 @@ __device__ __forceinline__ void expand_px_tiles(const float* Xs, const float* We
     constexpr int LDX = CINP + 4;
     const int frow = lane & 15, fk = (lane >> 4) * 4;
     const int pts[2] = {pt0, pt1};
+    // accumulators start at the folded BatchNorm shift (the scale is folded into the weights)
     f32x4 ea[NP][3];
 #pragma unroll
-    for (int q = 0; q < NP; ++q)
+    for (int ct = 0; ct < 3; ++ct) {
+        const f32x4 sh = *reinterpret_cast<const f32x4*>(Ps + Ce + ce0 + ct * 16 + (lane >> 4) * 4);
 #pragma unroll
-        for (int ct = 0; ct < 3; ++ct) ea[q][ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int q = 0; q < NP; ++q) ea[q][ct] = sh;
+    }
 #pragma unroll
     for (int kc = 0; kc < CINP / 16; ++kc) {
         f32x4 xb4[NP], wa[3];
@@ -69,14 +102,9 @@ __device__ __forceinline__ void expand_px_tiles(const float* Xs, const float* We
 #pragma unroll
         for (int ct = 0; ct < 3; ++ct) {
             const int cl = ct * 16 + (lane >> 4) * 4;
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (inimg) {
-                const f32x4 sc = *reinterpret_cast<const f32x4*>(Ps + ce0 + cl);
-                const f32x4 sh = *reinterpret_cast<const f32x4*>(Ps + Ce + ce0 + cl);
-                v = ea[q][ct] * sc + sh;
+            f32x4 v = ea[q][ct];
 #pragma unroll
-                for (int j = 0; j < 4; ++j) v[j] = relu6f(v[j]);
-            }
+            for (int j = 0; j < 4; ++j) v[j] = inimg ? relu6f(v[j]) : 0.0f;
             *reinterpret_cast<f32x4*>(Es + hp * kLDE + cl) = v;
         }
     }
@@ -111,37 +139,38 @@ __global__ __launch_bounds__(256, 2) void mbv2_block_kernel(const FusedBlockPara
     float* Ds = Es + IPXP * kLDE;           // [OPX][kLDE]
     float* Wes = Ds + OPX * kLDE;           // [kCK][LDX]
     float* Wps = Wes + kCK * LDX;           // [NTC*16][kLDE]
-    float* Ps = Wps + NTC * 16 * kLDE;      // [13][Ce]: es, eh, wd[9], ds, dh
+    float* Ps = Wps + NTC * 16 * kLDE;      // [13][Ce]: es, eh, wd[9], ds, dh; then [2][NTC*16]: ps, ph
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     long long tacc[6] = {0, 0, 0, 0, 0, 0};
     long long t0 = p.dbg ? clock64() : 0;
 #define TICK(i) do { if (p.dbg) { const long long t1 = clock64(); tacc[i] += t1 - t0; t0 = t1; } } while (0)
+    const bool getenv_dbg_split = p.dbg != nullptr;
     const int Ce = p.Ce;
     const int tiles_per_img = p.tiles_y * p.tiles_x;
     const long total_tiles = (long)p.B * tiles_per_img;
 
     // ---- weight chunk prefetch (global -> registers -> LDS)
     f32x4 wer[WE_R], wpr[WP_R], xr[X_R];
+    // (indices are clamped instead of predicated: every lane always loads from a valid
+    //  address, the stores below drop the lanes that are out of range)
     auto load_w = [&](int chunk) {
 #pragma unroll
         for (int i = 0; i < WE_R; ++i) {
-            const int u = tid + i * 256;
+            const int u = min(tid + i * 256, WE_U - 1);
             const int row = u / (CINP / 4), k4 = (u - row * (CINP / 4)) * 4;
-            wer[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-            if (u < WE_U && k4 < p.kpad_e)
-                wer[i] = *reinterpret_cast<const f32x4*>(p.we + (long)(chunk * kCK + row) * p.kpad_e + k4);
+            wer[i] = gload16_async(p.we + (long)(chunk * kCK + row) * p.kpad_e + k4);
         }
 #pragma unroll
         for (int i = 0; i < WP_R; ++i) {
-            const int u = tid + i * 256;
-            const int row = u / (kCK / 4), k4 = (u - row * (kCK / 4)) * 4;
-            wpr[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-            if (u < WP_U && row < p.npad_p)
-                wpr[i] = *reinterpret_cast<const f32x4*>(p.wp + (long)row * p.kpad_p + chunk * kCK + k4);
+            const int u = min(tid + i * 256, WP_U - 1);
+            const int row = min(u / (kCK / 4), p.npad_p - 1), k4 = (u % (kCK / 4)) * 4;
+            wpr[i] = gload16_async(p.wp + (long)row * p.kpad_p + chunk * kCK + k4);
         }
     };
     auto store_w = [&]() {
+        wait_prefetch(wer);
+        wait_prefetch(wpr);
 #pragma unroll
         for (int i = 0; i < WE_R; ++i) {
             const int u = tid + i * 256;
@@ -167,18 +196,25 @@ __global__ __launch_bounds__(256, 2) void mbv2_block_kernel(const FusedBlockPara
             const int u = tid + i * 256;
             const int hp = u / (CINP / 4), k4 = (u - hp * (CINP / 4)) * 4;
             const int r = hp / IW, c = hp - r * IW;
-            const int iy = iy0 + r, ix = ix0 + c;
-            xr[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-            if (u < X_U && hp < IPX && k4 < p.Cin && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W)
-                xr[i] = *reinterpret_cast<const f32x4*>(xb + ((long)iy * p.W + ix) * p.Cin + k4);
+            const int iy = min(max(iy0 + r, 0), p.H - 1), ix = min(max(ix0 + c, 0), p.W - 1);
+            xr[i] = gload16_async(xb + ((long)iy * p.W + ix) * p.Cin + min(k4, p.Cin - 4));
         }
     };
-    auto store_x = [&]() {
+    // the zero padding (outside the image / beyond Cin / beyond the halo) is applied here
+    auto store_x = [&](long t) {
+        const int b = (int)(t / tiles_per_img);
+        const int rem = (int)(t - (long)b * tiles_per_img);
+        const int ty = rem / p.tiles_x, tx = rem - ty * p.tiles_x;
+        const int iy0 = ty * TH * S - p.pad_t, ix0 = tx * TW * S - p.pad_l;
+        wait_prefetch(xr);
 #pragma unroll
         for (int i = 0; i < X_R; ++i) {
             const int u = tid + i * 256;
             const int hp = u / (CINP / 4), k4 = (u - hp * (CINP / 4)) * 4;
-            if (u < X_U) *reinterpret_cast<f32x4*>(Xs + hp * LDX + k4) = xr[i];
+            const int r = hp / IW, c = hp - r * IW;
+            const bool ok = hp < IPX && k4 < p.Cin && (unsigned)(iy0 + r) < (unsigned)p.H &&
+                            (unsigned)(ix0 + c) < (unsigned)p.W;
+            if (u < X_U) *reinterpret_cast<f32x4*>(Xs + hp * LDX + k4) = ok ? xr[i] : f32x4{0.f, 0.f, 0.f, 0.f};
         }
     };
 
@@ -193,7 +229,11 @@ __global__ __launch_bounds__(256, 2) void mbv2_block_kernel(const FusedBlockPara
                                                                    : p.wd + (long)(row - 2) * Ce;
         *reinterpret_cast<f32x4*>(Ps + row * Ce + c4) = *reinterpret_cast<const f32x4*>(src + c4);
     }
-    store_x();
+    for (int u = tid; u < 2 * NTC * 16; u += 256) {
+        const int row = u / (NTC * 16), n = u - row * (NTC * 16);
+        Ps[13 * Ce + u] = n < p.Cout ? (row == 0 ? p.ps[n] : p.ph[n]) : 0.f;
+    }
+    store_x(tile);
     store_w();
     __syncthreads();
     TICK(0);
@@ -215,15 +255,20 @@ __global__ __launch_bounds__(256, 2) void mbv2_block_kernel(const FusedBlockPara
         const long next = tile + gridDim.x;
         f32x4 acc[NTW];
 #pragma unroll
-        for (int i = 0; i < NTW; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int i = 0; i < NTW; ++i)
+            acc[i] = *reinterpret_cast<const f32x4*>(Ps + 13 * Ce + NTC * 16 + (wn * NTW + i) * 16 + (lane >> 4) * 4);
 
         for (int ch = 0; ch < nchunk; ++ch) {
             const int ce0 = ch * kCK;
-            if (ch + 1 < nchunk) {
-                load_w(ch + 1);
-            } else if (next < total_tiles) {       // last chunk: prefetch the next tile
-                load_w(0);
-                load_x(next);
+            // Prefetch (asm loads, see gload16_async): the next chunk's weights -- chunk 0 of the
+            // next tile during the last chunk -- and on the last chunk the next tile's input halo.
+            // A prefetch is issued ONLY if it will be consumed: the compiler treats the
+            // destination VGPRs of an unconsumed asm load as dead and would reuse them while
+            // the load is still in flight.
+            {
+                const bool last = ch + 1 == nchunk, has_next = next < total_tiles;
+                if (!last || has_next) load_w(last ? 0 : ch + 1);
+                if (last && has_next) load_x(next);
             }
 
             // ---- phase A: expand (MFMA): wave handles halo pixel tiles wave, wave+4, ...
@@ -234,14 +279,18 @@ __global__ __launch_bounds__(256, 2) void mbv2_block_kernel(const FusedBlockPara
                 if (pt < NPT)
                     expand_px_tiles<1, CINP, IW, IPX>(Xs, Wes, Es, Ps, Ce, ce0, pt, pt, lane, iy0, ix0, p.H, p.W);
             }
-            __syncthreads();
+            if (getenv_dbg_split) TICK(4);      // diagnostics: slot 4 = expand compute (+ weight staging), slot 1 = its barrier wait
+            lds_barrier();
             TICK(1);
 
             // ---- phase B: depthwise 3x3 + BN + ReLU6 (VALU, LDS -> LDS), sliding register window
             if (tid < NSTRIP * (kCK / 4)) {
                 f32x4 a[SL];
+                {
+                    const f32x4 sh = *reinterpret_cast<const f32x4*>(Ps + 12 * Ce + ce0 + bc4);
 #pragma unroll
-                for (int t = 0; t < SL; ++t) a[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    for (int t = 0; t < SL; ++t) a[t] = sh;
+                }
 #pragma unroll
                 for (int ky = 0; ky < 3; ++ky) {
                     f32x4 e[NIN];
@@ -261,17 +310,15 @@ __global__ __launch_bounds__(256, 2) void mbv2_block_kernel(const FusedBlockPara
                         }
                     }
                 }
-                const f32x4 sc = *reinterpret_cast<const f32x4*>(Ps + 11 * Ce + ce0 + bc4);
-                const f32x4 sh = *reinterpret_cast<const f32x4*>(Ps + 12 * Ce + ce0 + bc4);
 #pragma unroll
                 for (int t = 0; t < SL; ++t) {
-                    f32x4 v = a[t] * sc + sh;
+                    f32x4 v = a[t];
 #pragma unroll
                     for (int j = 0; j < 4; ++j) v[j] = relu6f(v[j]);
                     *reinterpret_cast<f32x4*>(Ds + (boy * TW + box0 + t) * kLDE + bc4) = v;
                 }
             }
-            __syncthreads();
+            lds_barrier();
             TICK(2);
 
             // ---- phase C: project (MFMA), accumulators stay in registers across chunks
@@ -288,11 +335,11 @@ __global__ __launch_bounds__(256, 2) void mbv2_block_kernel(const FusedBlockPara
                     for (int ni = 0; ni < NTW; ++ni)
                         acc[ni] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[ni][s], db[s], acc[ni], 0, 0, 0);
             }
-            __syncthreads();
+            lds_barrier();
             TICK(3);
             if (ch + 1 < nchunk) {
                 store_w();
-                __syncthreads();
+                lds_barrier();
             }
             TICK(4);
         }
@@ -307,9 +354,7 @@ __global__ __launch_bounds__(256, 2) void mbv2_block_kernel(const FusedBlockPara
             for (int ni = 0; ni < NTW; ++ni) {
                 const int n = (wn * NTW + ni) * 16 + (lane >> 4) * 4;
                 if (n >= p.Cout) continue;
-                const f32x4 sc = *reinterpret_cast<const f32x4*>(p.ps + n);
-                const f32x4 sh = *reinterpret_cast<const f32x4*>(p.ph + n);
-                f32x4 v = acc[ni] * sc + sh;
+                f32x4 v = acc[ni];
                 if (RES) {
                     // stride 1: the output pixel's input is halo pixel (oy + 1, ox + 1)
                     const f32x4 xres = *reinterpret_cast<const f32x4*>(Xs + ((oy + 1) * IW + ox + 1) * LDX + n);
@@ -319,10 +364,10 @@ __global__ __launch_bounds__(256, 2) void mbv2_block_kernel(const FusedBlockPara
             }
         }
         if (next < total_tiles) {
-            __syncthreads();          // every wave is done with Xs (residual) before it is replaced
-            store_x();
+            lds_barrier();          // every wave is done with Xs (residual) before it is replaced
+            store_x(next);
             store_w();
-            __syncthreads();
+            lds_barrier();
         }
         TICK(5);
     }
@@ -387,12 +432,188 @@ int launch_fused_block(FusedBlockParams p, hipStream_t st) {
         if (hipDeviceGetAttribute(&num_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || num_cu <= 0)
             num_cu = 256;
     }
-    const long blocks = tiles < 2L * num_cu ? tiles : 2L * num_cu;      // persistent: 2 workgroups per CU
-    const size_t lds = (c->static_floats + (size_t)13 * p.Ce) * sizeof(float);
+    static int per_cu = 0;
+    if (!per_cu) {
+        const char* e = getenv("SSD_FUSED_BLOCKS_PER_CU");      // diagnostics knob
+        per_cu = e ? atoi(e) : 2;
+        if (per_cu < 1) per_cu = 2;
+    }
+    const long blocks = tiles < (long)per_cu * num_cu ? tiles : (long)per_cu * num_cu;   // persistent workgroups
+    const size_t lds = (c->static_floats + (size_t)13 * p.Ce + (size_t)2 * c->ntc * 16) * sizeof(float);
     SSD_UNSUPPORTED_IF(lds > 160 * 1024, "fused block: needs %zu B of LDS", lds);
     if (lds > 64 * 1024)
         SSD_HIP(hipFuncSetAttribute((const void*)c->fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(c->fn, dim3((unsigned)blocks), dim3(256), lds, st, p);
+    SSD_LAUNCH_CHECK();
+    return SSD_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// Fused MobileNetV2 stem: Conv1 (3x3 stride 2, 3 -> 32, BN, ReLU6) -> expanded_conv_depthwise
+// (3x3, BN, ReLU6) -> expanded_conv_project (1x1, 32 -> 16, BN).  Unfused these three layers
+// move 830 MB per 64-image batch (two 184 MB 32-channel maps written and re-read); fused, the
+// 300x300x3 image goes in and the 150x150x16 map comes out.  One workgroup = 8 x 16 output
+// pixels: image patch -> LDS, Conv1 on the 10 x 18 halo (VALU, weights broadcast from LDS,
+// zero outside the feature map because the depthwise pads Conv1's OUTPUT), depthwise from LDS
+// (sliding window), project on the fp32 MFMA (K = 32), 16-byte stores.
+constexpr int kSTH = 8, kSTW = 16;
+constexpr int kSIH = kSTH + 2, kSIW = kSTW + 2;           // Conv1 halo tile 10 x 18
+constexpr int kSPH = 2 * (kSIH - 1) + 3, kSPW = 2 * (kSIW - 1) + 3;   // image patch 21 x 37
+constexpr int kSLD = 36;                                  // LDS row stride of the 32-channel tiles
+
+__global__ __launch_bounds__(256) void mbv2_stem_kernel(const StemParams p) {
+    __shared__ __attribute__((aligned(16))) float sm[kSPH * kSPW * 3 + 5 + kSIH * kSIW * kSLD + kSTH * kSTW * kSLD +
+                                                       27 * 32 + 9 * 32 + 16 * kSLD + 32 * 2 + 32 * 2 + 16 * 2];
+    float* patch = sm;                                         // [21*37*3] image patch (+5 pad)
+    float* C1 = patch + kSPH * kSPW * 3 + 5;                   // [180][36] Conv1 output (halo), 16-byte aligned
+    float* D = C1 + kSIH * kSIW * kSLD;                        // [128][36] depthwise output
+    float* W1 = D + kSTH * kSTW * kSLD;                        // [27][32] Conv1 weights * BN scale
+    float* Wd = W1 + 27 * 32;                                  // [9][32]  depthwise weights * BN scale
+    float* Wp = Wd + 9 * 32;                                   // [16][36] project weights * BN scale
+    float* H1 = Wp + 16 * kSLD;                                // [32] Conv1 BN shift
+    float* Hd = H1 + 32;                                       // [32] depthwise BN shift
+    float* Hp = Hd + 32;                                       // [16] project BN shift
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // weights (BatchNorm scale folded in) are staged once per persistent workgroup
+    for (int e = tid; e < 27 * 32; e += 256) {                 // packed [n][kpad] -> [k][n]
+        const int k = e >> 5, n = e & 31;
+        W1[e] = p.w1[(long)n * p.kpad1 + k] * p.s1[n];
+    }
+    for (int e = tid; e < 9 * 32; e += 256) Wd[e] = p.wd[e] * p.sd[e & 31];
+    for (int e = tid; e < 16 * 32; e += 256) {
+        const int n = e >> 5, k = e & 31;
+        Wp[n * kSLD + k] = p.wp[(long)n * p.kpadp + k] * p.sp[n];
+    }
+    if (tid < 32) { H1[tid] = p.h1[tid]; Hd[tid] = p.hd[tid]; }
+    if (tid < 16) Hp[tid] = p.hp[tid];
+
+    const int tiles_per_img = p.tiles_y * p.tiles_x;
+    const long total_tiles = (long)p.B * tiles_per_img;
+    for (long tile = blockIdx.x; tile < total_tiles; tile += gridDim.x) {
+        const int b = (int)(tile / tiles_per_img);
+        const int rem = (int)(tile - (long)b * tiles_per_img);
+        const int ty = rem / p.tiles_x, tx = rem - ty * p.tiles_x;
+        const int oy0 = ty * kSTH, ox0 = tx * kSTW;               // output tile origin (150 x 150 grid)
+        const int cy0 = oy0 - 1, cx0 = ox0 - 1;                    // Conv1-output halo origin (dw SAME pad 1)
+        const int iy0 = cy0 * 2 - p.pad_t, ix0 = cx0 * 2 - p.pad_l;   // image patch origin
+        const float* img = p.x + (long)b * p.H * p.W * 3;
+
+        __syncthreads();        // previous tile fully consumed (and the weights are visible)
+        // image patch: 21 rows x 111 contiguous floats
+        {
+            constexpr int NP = (kSPH * kSPW * 3 + 255) / 256;
+            float tmp[NP];
+#pragma unroll
+            for (int i = 0; i < NP; ++i) {                         // all loads in flight together
+                const int e = tid + i * 256;
+                const int r = e / (kSPW * 3), j = e - r * (kSPW * 3);
+                const int iy = iy0 + r, ixc = ix0 * 3 + j;         // ixc = ix * 3 + channel
+                tmp[i] = 0.f;
+                if (e < kSPH * kSPW * 3 && (unsigned)iy < (unsigned)p.H && ixc >= 0 && ixc < p.W * 3)
+                    tmp[i] = img[(long)iy * p.W * 3 + ixc];
+            }
+#pragma unroll
+            for (int i = 0; i < NP; ++i) {
+                const int e = tid + i * 256;
+                if (e < kSPH * kSPW * 3) patch[e] = tmp[i];
+            }
+        }
+        __syncthreads();
+
+        // ---- Conv1 on the halo: item = (halo pixel, 8-channel group)
+        for (int it = tid; it < kSIH * kSIW * 4; it += 256) {
+            const int cg = (it & 3) * 8, hp = it >> 2;
+            const int r = hp / kSIW, c = hp - r * kSIW;
+            f32x4 a0 = *reinterpret_cast<const f32x4*>(H1 + cg), a1 = *reinterpret_cast<const f32x4*>(H1 + cg + 4);
+            const float* pp = patch + ((2 * r) * kSPW + 2 * c) * 3;
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                for (int kk = 0; kk < 9; ++kk) {                    // (kx, ci) are contiguous in the patch row
+                    const float x = pp[ky * kSPW * 3 + kk];
+                    const float* wk = W1 + (ky * 9 + kk) * 32 + cg;
+                    const f32x4 w0 = *reinterpret_cast<const f32x4*>(wk), w1 = *reinterpret_cast<const f32x4*>(wk + 4);
+                    a0[0] = fmaf(x, w0[0], a0[0]); a0[1] = fmaf(x, w0[1], a0[1]);
+                    a0[2] = fmaf(x, w0[2], a0[2]); a0[3] = fmaf(x, w0[3], a0[3]);
+                    a1[0] = fmaf(x, w1[0], a1[0]); a1[1] = fmaf(x, w1[1], a1[1]);
+                    a1[2] = fmaf(x, w1[2], a1[2]); a1[3] = fmaf(x, w1[3], a1[3]);
+                }
+            const bool in = (unsigned)(cy0 + r) < (unsigned)p.H1 && (unsigned)(cx0 + c) < (unsigned)p.W1;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { a0[j] = in ? relu6f(a0[j]) : 0.f; a1[j] = in ? relu6f(a1[j]) : 0.f; }
+            *reinterpret_cast<f32x4*>(C1 + hp * kSLD + cg) = a0;
+            *reinterpret_cast<f32x4*>(C1 + hp * kSLD + cg + 4) = a1;
+        }
+        __syncthreads();
+
+        // ---- depthwise: thread = 4 channels x 4 consecutive columns (8 rows x 4 strips x 8 groups = 256)
+        {
+            const int c4 = (tid & 7) * 4, strip = tid >> 3;
+            const int oy = strip >> 2, ox = (strip & 3) * 4;
+            f32x4 a[4];
+            const f32x4 sh = *reinterpret_cast<const f32x4*>(Hd + c4);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) a[t] = sh;
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky) {
+                f32x4 e[6];
+#pragma unroll
+                for (int j = 0; j < 6; ++j) e[j] = *reinterpret_cast<const f32x4*>(C1 + ((oy + ky) * kSIW + ox + j) * kSLD + c4);
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx) {
+                    const f32x4 w = *reinterpret_cast<const f32x4*>(Wd + (ky * 3 + kx) * 32 + c4);
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        a[t][0] = fmaf(e[t + kx][0], w[0], a[t][0]); a[t][1] = fmaf(e[t + kx][1], w[1], a[t][1]);
+                        a[t][2] = fmaf(e[t + kx][2], w[2], a[t][2]); a[t][3] = fmaf(e[t + kx][3], w[3], a[t][3]);
+                    }
+                }
+            }
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                f32x4 v = a[t];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] = relu6f(v[j]);
+                *reinterpret_cast<f32x4*>(D + (oy * kSTW + ox + t) * kSLD + c4) = v;
+            }
+        }
+        __syncthreads();
+
+        // ---- project 32 -> 16 on the MFMA: wave handles pixel tiles wave, wave + 4 (8 tiles of 16 px)
+        const int frow = lane & 15, fk = (lane >> 4) * 4;
+        f32x4 acc[2];
+        acc[0] = acc[1] = *reinterpret_cast<const f32x4*>(Hp + (lane >> 4) * 4);
+#pragma unroll
+        for (int kc = 0; kc < 2; ++kc) {
+            const f32x4 wa = *reinterpret_cast<const f32x4*>(Wp + frow * kSLD + kc * 16 + fk);
+            f32x4 db[2];
+#pragma unroll
+            for (int q = 0; q < 2; ++q) db[q] = *reinterpret_cast<const f32x4*>(D + ((wave + 4 * q) * 16 + frow) * kSLD + kc * 16 + fk);
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+#pragma unroll
+                for (int q = 0; q < 2; ++q) acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[s], db[q][s], acc[q], 0, 0, 0);
+        }
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int po = (wave + 4 * q) * 16 + (lane & 15);
+            const int oy = oy0 + po / kSTW, ox = ox0 + po % kSTW;
+            if (oy < p.H1 && ox < p.W1)
+                *reinterpret_cast<f32x4*>(p.y + (((long)b * p.H1 + oy) * p.W1 + ox) * 16 + (lane >> 4) * 4) = acc[q];
+        }
+    }
+}
+
+bool stem_supported(const StemParams& p) { return p.H1 >= 1 && p.W1 >= 1; }
+
+int launch_stem(StemParams p, hipStream_t st) {
+    if (p.B == 0) return SSD_OK;
+    p.tiles_y = (p.H1 + kSTH - 1) / kSTH;
+    p.tiles_x = (p.W1 + kSTW - 1) / kSTW;
+    const long tiles = (long)p.B * p.tiles_y * p.tiles_x;
+    const long blocks = tiles < 512 ? tiles : 512;           // persistent: 2 workgroups per CU
+    hipLaunchKernelGGL(mbv2_stem_kernel, dim3((unsigned)blocks), dim3(256), 0, st, p);
     SSD_LAUNCH_CHECK();
     return SSD_OK;
 }

@@ -57,8 +57,11 @@ struct Layer {
     // fused inverted-residual block: LK_FUSED layer points at its three member layers;
     // members carry the index of their LK_FUSED layer in `fused_by`
     int f_expand = -1, f_dw = -1, f_project = -1;
+    int f_type = 0;                 // 0: inverted-residual block, 1: stem (Conv1 -> dw -> project)
     int fused_by = -1;
     float* splitk_part = nullptr;   // this layer's own split-K slab (layers may run concurrently)
+    // LK_FUSED: weight copies with the folded BatchNorm scale multiplied in (per output channel)
+    float *fz_we = nullptr, *fz_wd = nullptr, *fz_wp = nullptr;
     int side = 0;                   // 1: runs on the side stream (SSD head convs)
     hipEvent_t ev_ready = nullptr;  // recorded on the main stream when this layer's OUTPUT is complete
 };
@@ -304,6 +307,19 @@ static void build_mobilenet_v2(ssd_net& net) {
                  SSD_ACT_RELU6);
     x = b.conv("expanded_conv_project", "expanded_conv_project_BN", x, 16, 1, 1, 1, 1, "expanded_conv_project_BN",
                false, SSD_ACT_NONE);
+    {   // fused stem: Conv1 -> expanded_conv_depthwise -> expanded_conv_project in one kernel
+        Layer f;
+        f.name = "stem_fused";
+        f.kind = LK_FUSED;
+        f.f_type = 1;
+        f.in = 0; f.out = x;
+        const Layer& l1 = net.layers[0];
+        f.H = l1.H; f.W = l1.W; f.Cin = 3; f.Ho = l1.Ho; f.Wo = l1.Wo; f.Cout = 16;
+        f.stride = 2; f.pt = l1.pt; f.pl = l1.pl;
+        net.layers.insert(net.layers.begin(), f);
+        net.layers[0].f_expand = 1; net.layers[0].f_dw = 2; net.layers[0].f_project = 3;
+        for (int j = 1; j <= 3; ++j) net.layers[j].fused_by = 0;
+    }
     static const int blocks[16][2] = {{24, 2}, {24, 1}, {32, 2}, {32, 1}, {32, 1}, {64, 2}, {64, 1}, {64, 1},
                                       {64, 1}, {96, 1}, {96, 1}, {96, 1}, {160, 2}, {160, 1}, {160, 1}, {320, 1}};
     int cin = 16, tap1 = -1;
@@ -429,15 +445,32 @@ static FusedBlockParams fused_params(const ssd_net& net, const Layer& f, int B) 
     FusedBlockParams p{};
     p.x = net.tensors[f.in].dev;
     p.y = net.tensors[f.out].dev;
-    p.we = le.packed; p.es = le.scale; p.eh = le.shift;
-    p.wd = net.params[ld.p_kernel].dev; p.ds = ld.scale; p.dh = ld.shift;
-    p.wp = lp.packed; p.ps = lp.scale; p.ph = lp.shift;
+    // scales are folded into the fz_* weight copies; the kernel only adds the shifts
+    p.we = f.fz_we; p.es = le.scale; p.eh = le.shift;
+    p.wd = f.fz_wd; p.ds = ld.scale; p.dh = ld.shift;
+    p.wp = f.fz_wp; p.ps = lp.scale; p.ph = lp.shift;
     p.residual = lp.res >= 0 ? 1 : 0;
     p.B = B; p.H = f.H; p.W = f.W; p.Cin = f.Cin; p.Ce = le.Cout; p.Cout = f.Cout;
     p.Ho = f.Ho; p.Wo = f.Wo; p.stride = f.stride; p.pad_t = f.pt; p.pad_l = f.pl;
     p.kpad_e = conv_kpad(le.Cin);
     p.kpad_p = conv_kpad(lp.Cin);
     p.npad_p = conv_npad(lp.Cout);
+    return p;
+}
+
+static StemParams stem_params(const ssd_net& net, const Layer& f, int B) {
+    const Layer& l1 = net.layers[f.f_expand];
+    const Layer& ld = net.layers[f.f_dw];
+    const Layer& lp = net.layers[f.f_project];
+    StemParams p{};
+    p.x = net.tensors[f.in].dev;
+    p.y = net.tensors[f.out].dev;
+    p.w1 = l1.packed; p.s1 = l1.scale; p.h1 = l1.shift;
+    p.wd = net.params[ld.p_kernel].dev; p.sd = ld.scale; p.hd = ld.shift;
+    p.wp = lp.packed; p.sp = lp.scale; p.hp = lp.shift;
+    p.B = B; p.H = f.H; p.W = f.W; p.H1 = f.Ho; p.W1 = f.Wo; p.pad_t = f.pt; p.pad_l = f.pl;
+    p.kpad1 = conv_kpad(27);
+    p.kpadp = conv_kpad(32);
     return p;
 }
 
@@ -461,6 +494,7 @@ static int run_layer(ssd_net& net, const Layer& l, int B, float* deltas_out, flo
         case LK_SOFTMAX:
             return launch_softmax(probs_out, (long)B * net.num_priors, net.L, probs_out, st);
         case LK_FUSED:
+            if (l.f_type == 1) return launch_stem(stem_params(net, l, B), st);
             return launch_fused_block(fused_params(net, l, B), st);
     }
     return SSD_OK;
@@ -469,7 +503,9 @@ static int run_layer(ssd_net& net, const Layer& l, int B, float* deltas_out, flo
 // A fused layer is active when fusion is on and the kernel supports its shape; then its
 // three member layers are skipped (and vice versa).
 static bool fused_active(const ssd_net& net, const Layer& f) {
-    return net.fuse_blocks && fused_block_supported(fused_params(net, f, 1));
+    if (!net.fuse_blocks) return false;
+    if (f.f_type == 1) return stem_supported(stem_params(net, f, 1));
+    return fused_block_supported(fused_params(net, f, 1));
 }
 static bool layer_runs(const ssd_net& net, const Layer& l) {
     if (l.kind == LK_FUSED) return fused_active(net, l);
@@ -730,6 +766,24 @@ int ssd_net_finalize(ssd_net* net, int max_batch) {
             }
         }
     }
+    // fused blocks: weight copies with the BatchNorm scale folded in
+    for (auto& f : net->layers) {
+        if (f.kind != LK_FUSED || f.f_type != 0) continue;
+        const Layer& le = net->layers[f.f_expand];
+        const Layer& ld = net->layers[f.f_dw];
+        const Layer& lp = net->layers[f.f_project];
+        const size_t ne = (size_t)conv_kpad(le.Cin) * conv_npad(le.Cout), nd = (size_t)9 * ld.Cout,
+                     np = (size_t)conv_kpad(lp.Cin) * conv_npad(lp.Cout);
+        int rc = dev_alloc(*net, ne, &f.fz_we);
+        if (!rc) rc = dev_alloc(*net, nd, &f.fz_wd);
+        if (!rc) rc = dev_alloc(*net, np, &f.fz_wp);
+        if (rc) return rc;
+        // packed [n][kpad]: row n scaled by scale[n]; depthwise [9][C]: column c scaled by scale[c]
+        rc = launch_scale_rows(le.packed, le.scale, conv_npad(le.Cout), le.Cout, conv_kpad(le.Cin), f.fz_we, st);
+        if (!rc) rc = launch_scale_cols(net->params[ld.p_kernel].dev, ld.scale, 9, ld.Cout, f.fz_wd, st);
+        if (!rc) rc = launch_scale_rows(lp.packed, lp.scale, conv_npad(lp.Cout), lp.Cout, conv_kpad(lp.Cin), f.fz_wp, st);
+        if (rc) return rc;
+    }
     // activation arena: one slot per tensor (288 GB of HBM: no aliasing needed, every
     // activation of the last forward stays inspectable)
     if (net->arena) (void)hipFree(net->arena);
@@ -967,7 +1021,7 @@ int ssd_net_profile_fused(ssd_net* net, const char* layer, int B, double* cycles
     if (!net->finalized) { set_error("ssd_net_profile_fused: not finalized"); return SSD_E_STATE; }
     const Layer* f = nullptr;
     for (const auto& l : net->layers)
-        if (l.kind == LK_FUSED && l.name == layer) f = &l;
+        if (l.kind == LK_FUSED && l.f_type == 0 && l.name == layer) f = &l;
     SSD_CHECK_ARG(f != nullptr, "ssd_net_profile_fused: unknown fused layer '%s'", layer);
     FusedBlockParams p = fused_params(*net, *f, B);
     SSD_CHECK_ARG(fused_block_supported(p), "ssd_net_profile_fused: layer not supported by the fused kernel");

@@ -240,6 +240,34 @@ __global__ void fold_bn_kernel(const float* gamma, const float* beta, const floa
     shift[c] = beta[c] - mean[c] * inv;
 }
 
+__global__ void scale_weights_kernel(const float* in, const float* scale, const int rows, const int nvalid,
+                                     const int cols, const int by_col, float* out) {
+    const long total = (long)rows * cols;
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+        const int r = (int)(e / cols), c = (int)(e - (long)r * cols);
+        const float s = by_col ? scale[c] : (r < nvalid ? scale[r] : 1.0f);
+        out[e] = in[e] * s;
+    }
+}
+
+int launch_scale_rows(const float* in, const float* scale, int rows, int nvalid, int cols, float* out, hipStream_t st) {
+    const long total = (long)rows * cols;
+    if (total == 0) return SSD_OK;
+    hipLaunchKernelGGL(scale_weights_kernel, dim3(cdiv(total, 256) < 1024 ? cdiv(total, 256) : 1024), dim3(256), 0, st,
+                       in, scale, rows, nvalid, cols, 0, out);
+    SSD_LAUNCH_CHECK();
+    return SSD_OK;
+}
+
+int launch_scale_cols(const float* in, const float* scale, int rows, int cols, float* out, hipStream_t st) {
+    const long total = (long)rows * cols;
+    if (total == 0) return SSD_OK;
+    hipLaunchKernelGGL(scale_weights_kernel, dim3(cdiv(total, 256) < 1024 ? cdiv(total, 256) : 1024), dim3(256), 0, st,
+                       in, scale, rows, rows, cols, 1, out);
+    SSD_LAUNCH_CHECK();
+    return SSD_OK;
+}
+
 int launch_fold_bn(const float* gamma, const float* beta, const float* mean, const float* var, float eps, int C,
                    float* scale, float* shift, hipStream_t st) {
     hipLaunchKernelGGL(fold_bn_kernel, dim3(cdiv(C, 256)), dim3(256), 0, st, gamma, beta, mean, var, eps, C,
