@@ -101,12 +101,14 @@ def main():
         decoder_model(x)
     info, nfw = model.read_timing(B)
     model.set_timing(False)
-    mfma = [r for r in info if r["kind"] == "conv" and r["config"].startswith("mfma_")]
+    mfma = [r for r in info if r["kind"] == "conv" and r["config"].startswith("mfma_") and r["flops"] > 0]
     mfma_ms = sum(r["ms"] for r in mfma)
     mfma_flops = sum(r["flops"] for r in mfma)
-    total_ms = sum(r["ms"] for r in info)
+    total_ms = sum(r["ms"] for r in info if r["flops"] > 0 or r["bytes"] > 0 or r["kind"] == "nms")
     kinds = {}
     for r in info:
+        if r["flops"] == 0 and r["bytes"] == 0 and r["kind"] != "nms":
+            continue                      # layer replaced by a fused kernel (only event overhead)
         k = r["kind"] if not (r["kind"] == "conv" and not r["config"].startswith("mfma_")) else "conv_direct"
         kinds[k] = kinds.get(k, 0.0) + r["ms"]
     achieved = mfma_flops / (mfma_ms * 1e-3) / 1e12 if mfma_ms > 0 else 0.0
