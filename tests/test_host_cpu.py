@@ -124,8 +124,12 @@ def test_two_process_gloo_gather(tmp_path):
     script = tmp_path / "worker.py"
     script.write_text(_WORKER % {"repo": REPO})
     env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    import socket
+    with socket.socket() as sk:                 # a free rendezvous port
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
     out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
-                          "--master-addr", "127.0.0.1", "--master-port", "29533", str(script)],
+                          "--master-addr", "127.0.0.1", "--master-port", str(port), str(script)],
                          env=env, capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "rank 0 ok" in out.stdout and "rank 1 ok" in out.stdout
