@@ -46,6 +46,7 @@ struct FusedBlockParams {
     int kpad_e, kpad_p, npad_p;
     int tiles_y, tiles_x;       // filled by the launcher
     long long* dbg;             // optional per-phase cycle counters [blocks][8] (profiling builds)
+    int ablate;                 // diagnostics: 1 skip expand MFMAs, 2 skip depthwise math, 4 skip project MFMAs, 8 skip expand epilogue math
 };
 // Fused MobileNetV2 stem (Conv1 -> expanded_conv_depthwise -> expanded_conv_project).
 struct StemParams {

@@ -64,7 +64,7 @@ template <int NP, int CINP, int IW, int IPX>
 __device__ __forceinline__ void expand_px_tiles(const float* Xs, const float* Wes, float* Es, const float* Ps,
                                                 const int Ce, const int ce0, const int pt0, const int pt1,
                                                 const int lane, const int iy0, const int ix0, const int H,
-                                                const int W) {
+                                                const int W, const int ablate = 0) {
     constexpr int LDX = CINP + 4;
     const int frow = lane & 15, fk = (lane >> 4) * 4;
     const int pts[2] = {pt0, pt1};
@@ -76,6 +76,7 @@ __device__ __forceinline__ void expand_px_tiles(const float* Xs, const float* We
 #pragma unroll
         for (int q = 0; q < NP; ++q) ea[q][ct] = sh;
     }
+    if (!(ablate & 1))
 #pragma unroll
     for (int kc = 0; kc < CINP / 16; ++kc) {
         f32x4 xb4[NP], wa[3];
@@ -103,6 +104,7 @@ __device__ __forceinline__ void expand_px_tiles(const float* Xs, const float* We
         for (int ct = 0; ct < 3; ++ct) {
             const int cl = ct * 16 + (lane >> 4) * 4;
             f32x4 v = ea[q][ct];
+            if (!(ablate & 8))
 #pragma unroll
             for (int j = 0; j < 4; ++j) v[j] = inimg ? relu6f(v[j]) : 0.0f;
             *reinterpret_cast<f32x4*>(Es + hp * kLDE + cl) = v;
@@ -275,16 +277,16 @@ __global__ __launch_bounds__(256, 2) void mbv2_block_kernel(const FusedBlockPara
             {
                 int pt = wave;
                 for (; pt + 4 < NPT; pt += 8)
-                    expand_px_tiles<2, CINP, IW, IPX>(Xs, Wes, Es, Ps, Ce, ce0, pt, pt + 4, lane, iy0, ix0, p.H, p.W);
+                    expand_px_tiles<2, CINP, IW, IPX>(Xs, Wes, Es, Ps, Ce, ce0, pt, pt + 4, lane, iy0, ix0, p.H, p.W, p.ablate);
                 if (pt < NPT)
-                    expand_px_tiles<1, CINP, IW, IPX>(Xs, Wes, Es, Ps, Ce, ce0, pt, pt, lane, iy0, ix0, p.H, p.W);
+                    expand_px_tiles<1, CINP, IW, IPX>(Xs, Wes, Es, Ps, Ce, ce0, pt, pt, lane, iy0, ix0, p.H, p.W, p.ablate);
             }
             if (getenv_dbg_split) TICK(4);      // diagnostics: slot 4 = expand compute (+ weight staging), slot 1 = its barrier wait
             lds_barrier();
             TICK(1);
 
             // ---- phase B: depthwise 3x3 + BN + ReLU6 (VALU, LDS -> LDS), sliding register window
-            if (tid < NSTRIP * (kCK / 4)) {
+            if (tid < NSTRIP * (kCK / 4) && !(p.ablate & 2)) {
                 f32x4 a[SL];
                 {
                     const f32x4 sh = *reinterpret_cast<const f32x4*>(Ps + 12 * Ce + ce0 + bc4);
@@ -322,6 +324,7 @@ __global__ __launch_bounds__(256, 2) void mbv2_block_kernel(const FusedBlockPara
             TICK(2);
 
             // ---- phase C: project (MFMA), accumulators stay in registers across chunks
+            if (!(p.ablate & 4))
 #pragma unroll
             for (int kc = 0; kc < kCK / 16; ++kc) {
                 const f32x4 db = *reinterpret_cast<const f32x4*>(Ds + (wpx * 16 + frow) * kLDE + kc * 16 + fk);

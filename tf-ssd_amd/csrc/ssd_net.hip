@@ -6,6 +6,7 @@
 // Reference graphs: models/ssd_mobilenet_v2.py:7-35 (+ [3P] keras-applications 1.0.8
 // MobileNetV2), models/ssd_vgg16.py:33-97, models/header.py:43-67.
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <memory>
@@ -1032,6 +1033,22 @@ int ssd_net_profile_fused(ssd_net* net, const char* layer, int B, double* cycles
     SSD_CHECK_ARG(f != nullptr, "ssd_net_profile_fused: unknown fused layer '%s'", layer);
     FusedBlockParams p = fused_params(*net, *f, B);
     SSD_CHECK_ARG(fused_block_supported(p), "ssd_net_profile_fused: layer not supported by the fused kernel");
+    if (const char* ab = getenv("SSD_FUSED_ABLATE")) {      // diagnostics: time the kernel with phases removed
+        p.ablate = atoi(ab);
+        hipEvent_t e0, e1;
+        (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+        (void)launch_fused_block(p, nullptr);
+        (void)hipEventRecord(e0, nullptr);
+        for (int r = 0; r < 10; ++r) (void)launch_fused_block(p, nullptr);
+        (void)hipEventRecord(e1, nullptr);
+        (void)hipEventSynchronize(e1);
+        float ms = 0.f;
+        (void)hipEventElapsedTime(&ms, e0, e1);
+        for (int i = 0; i < 6; ++i) cycles_out6[i] = 0;
+        cycles_out6[0] = ms * 100.0;        // microseconds per launch
+        (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+        return SSD_OK;
+    }
     const size_t n = (size_t)B * 4096 * 4 * 6;     // upper bound: <= 4096 tiles per image
     long long* d = nullptr;
     SSD_HIP(hipMalloc((void**)&d, n * sizeof(long long)));
