@@ -36,6 +36,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=None, help="images per GPU per step (default 64 / 32 for vgg16)")
     ap.add_argument("--backbone", default="mobilenet_v2", choices=["mobilenet_v2", "vgg16"])
+    ap.add_argument("--img-size", type=int, default=300, help="300 (reference configs) or 512 (BASELINE configs[4] graph)")
     ap.add_argument("--cpu-sample", type=int, default=8, help="images per pass of the CPU baseline")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--layers", action="store_true", help="also print the per-layer table to stderr")
@@ -66,6 +67,19 @@ def main():
     B = args.batch or (64 if args.backbone == "mobilenet_v2" else 32)
     hp = dict(train_utils.get_hyper_params(args.backbone))
     hp["total_labels"] = 21                      # "bg" + 20 VOC classes (predictor.py:25-27)
+    if args.img_size != 300:                     # not a reference config: same graph at another size
+        hp["img_size"] = args.img_size
+        s_, fm = args.img_size, []
+        if args.backbone == "mobilenet_v2":
+            for div in (16, 32):
+                fm.append(-(-s_ // div))
+            t = fm[-1]
+            for _ in range(4):
+                t = -(-t // 2)
+                fm.append(t)
+        else:
+            raise SystemExit("--img-size is wired for mobilenet_v2 only")
+        hp["feature_map_shapes"] = fm
     model = get_model(hp, max_batch=B)
     weights = data_utils.synthetic_weights(model, seed=1)
     priors = bbox_utils.generate_prior_boxes(hp["feature_map_shapes"], hp["aspect_ratios"])
@@ -119,7 +133,7 @@ def main():
                 r["flops"] / max(r["ms"], 1e-9) / 1e9, r["bytes"] / max(r["ms"], 1e-9) / 1e6))
 
     result = {
-        "metric": "images/sec SSD300 (%s) fwd+NMS" % ("MobileNetV2" if args.backbone == "mobilenet_v2" else "VGG16"),
+        "metric": "images/sec SSD%d (%s) fwd+NMS" % (hp["img_size"], "MobileNetV2" if args.backbone == "mobilenet_v2" else "VGG16"),
         "value": world * B * args.steps / elapsed,
         "unit": "images/sec",
         "n_gpus": world,
@@ -131,8 +145,9 @@ def main():
         "vs_baseline": None,
         "dtype": "f32",
         "data": "synthetic (seeded uniform [0,1) images, seeded random weights; no dataset/checkpoint offline)",
-        "config": {"workload": "SSD300 %s inference, batch=%d per GPU, 300x300 fp32, fwd + decode/NMS (BASELINE.json configs[%d])" % (
-                       args.backbone, B, 1 if args.backbone == "mobilenet_v2" else 2),
+        "config": {"workload": "SSD%d %s inference, batch=%d per GPU, %dx%d fp32, fwd + decode/NMS (BASELINE.json configs[%d])" % (
+                       hp["img_size"], args.backbone, B, hp["img_size"], hp["img_size"],
+                       (1 if args.backbone == "mobilenet_v2" else 2) if hp["img_size"] == 300 else 4),
                    "global_batch": world * B, "priors": model.num_priors, "labels": hp["total_labels"],
                    "mean_detections_per_image": mean_det, "parallelism": "batch-sharded x%d, no collective" % world},
         "roofline": {"bound": "mfma", "kernel": "conv_mfma_kernel (fp32 v_mfma_f32_16x16x4 implicit-GEMM conv, all tile configs)",

@@ -38,7 +38,11 @@ def run_conv(x, w, scale=None, shift=None, res=None, stride=1, dil=1, pads=(0, 0
     d = h.ConvDesc(B, H, W, Cin, Cout, kh, kw, stride, dil, pads[0], pads[2], pads[1], pads[3], act,
                    int(res is not None))
     xd, wd = h.to_dev(x), h.to_dev(w)
-    packed = torch.empty(lib.ssd_conv_packed_weight_floats(kh, kw, Cin, Cout), dtype=torch.float32, device=xd.device)
+    # the packed weights are followed by NaN poison: a kernel that reads past [Npad][Kpad]
+    # (and multiplies by a zero-padded pixel) turns the output NaN
+    npk = lib.ssd_conv_packed_weight_floats(kh, kw, Cin, Cout)
+    poisoned = torch.full((npk + 4096,), float("nan"), dtype=torch.float32, device=xd.device)
+    packed = poisoned[:npk]
     h.check(lib.ssd_conv_pack_weights(h.ptr(wd), kh, kw, Cin, Cout, h.ptr(packed), h.stream()), "pack")
     Ho = lib.ssd_conv_out_size(H, kh, stride, dil, pads[0], pads[1])
     Wo = lib.ssd_conv_out_size(W, kw, stride, dil, pads[2], pads[3])
@@ -356,3 +360,73 @@ def test_conv2d_every_config_and_split_on_net_shapes(H, Cin, Cout, k, stride):
             assert err <= 1e-4 * max(1.0, float(np.abs(ref).max())), (lib.ssd_conv_config_name(cfg), split, err)
             ran += 1
     assert ran >= 20
+
+
+def test_mobilenet_v2_ssd512_forward_parity():
+    """BASELINE config 5 graph: the same MobileNetV2-SSD at 512x512 (feature maps 32,16,8,4,2,1,
+    6132 priors; every stride-2 depthwise pads (0,1) because all its inputs are even)."""
+    from models.ssd_mobilenet_v2 import get_model
+    from utils import bbox_utils
+    hp = helpers.hyper_params("mobilenet_v2")
+    hp["img_size"] = 512
+    hp["feature_map_shapes"] = [32, 16, 8, 4, 2, 1]
+    w = helpers.synthetic_weights("mobilenet_v2", hp)
+    m = get_model(hp)
+    m.set_weights(w)
+    assert m.num_priors == 6132
+    x = helpers.images(1, 512, seed=3)
+    acts = {}
+    rd, rp = no.forward("mobilenet_v2", hp, w, x, acts)
+    d, p = m(x)
+    assert _np(d).shape == (1, 6132, 4) and _np(p).shape == (1, 6132, 21)
+    for name in ("block_3_out", "block_6_out", "out_relu", "extra4_2"):
+        _close(m.fetch_activation(name).reshape(acts[name].shape), acts[name])
+    assert np.abs(_np(p) - rp).max() <= 1e-4
+    _close(_np(d), rd)
+    pri = bbox_utils.generate_prior_boxes(hp["feature_map_shapes"], hp["aspect_ratios"])
+    assert tuple(pri.shape) == (6132, 4)
+    with pytest.raises(ValueError):          # feature_map_shapes must match the graph at this img_size
+        bad = dict(hp); bad["feature_map_shapes"] = [19, 10, 5, 3, 2, 1]
+        get_model(bad)
+
+
+def test_weights_container_roundtrip(tmp_path, mbv2):
+    """N3: .npz weights container keyed by Keras variable names."""
+    from models.ssd_mobilenet_v2 import get_model
+    m, hp, w = mbv2
+    path = str(tmp_path / "ssd_mobilenet_v2_model_weights.h5")
+    m.save_weights(path)
+    m2 = get_model(hp)
+    m2.load_weights(path)
+    x = helpers.images(1, 300, seed=5)
+    d1, p1 = m(x)
+    d2, p2 = m2(x)
+    w2 = m2.get_weights()
+    assert set(w2) == set(w)
+    for k in w:
+        np.testing.assert_array_equal(w2[k], np.asarray(w[k], np.float32))
+    # the two nets autotune independently (different tiles / split-K => different summation order)
+    assert np.abs(_np(p1) - _np(p2)).max() <= 1e-5
+    _close(_np(d1), _np(d2), tol=1e-5)
+
+
+def test_conv_bk64_tiles_do_not_read_past_packed_weights():
+    """K = 32 / 96 / 160 (Kpad a multiple of 32 but not of 64) under every BK=64 tile config:
+    the last k-tile must not touch memory past the packed [Npad][Kpad] weights (NaN-poisoned
+    in run_conv) -- this faulted in ssd_net_finalize's autotune on block_4_expand."""
+    import ssd_hip as h
+    lib = h.lib()
+    rng = np.random.default_rng(21)
+    ran = 0
+    for Cin, Cout in ((32, 192), (96, 576), (160, 960)):
+        x = rng.standard_normal((2, 10, 10, Cin)).astype(np.float32)
+        w = (rng.standard_normal((1, 1, Cin, Cout)) / np.sqrt(Cin)).astype(np.float32)
+        ref = no.conv2d(x, w, None, 1, 1, "valid")
+        for c in range(lib.ssd_conv_num_configs()):
+            if b"k64" not in lib.ssd_conv_config_name(c):
+                continue
+            rc, out = run_conv(x, w, cfg=c)
+            assert rc == 0, h.last_error()
+            _close(_np(out), ref)
+            ran += 1
+    assert ran > 0

@@ -110,7 +110,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvParams p) {
             const int u = tid + ps * 256;
             const int n = n0 + u / UPR;
             wr[ps] = f32x4{0.f, 0.f, 0.f, 0.f};
-            if (u < WU && n < p.Npad)
+            if (u < WU && n < p.Npad && k0 + kq4 < p.Kpad)   // BK=64 tiles over a Kpad that is only a multiple of 32
                 wr[ps] = *reinterpret_cast<const f32x4*>(p.w + (long)n * p.Kpad + k0 + kq4);
         }
     };

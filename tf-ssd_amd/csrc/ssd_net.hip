@@ -475,8 +475,23 @@ static StemParams stem_params(const ssd_net& net, const Layer& f, int B) {
     return p;
 }
 
+static int run_layer_impl(ssd_net& net, const Layer& l, int B, float* deltas_out, float* probs_out, hipStream_t st,
+                          int cfg_override);
+
 static int run_layer(ssd_net& net, const Layer& l, int B, float* deltas_out, float* probs_out, hipStream_t st,
                      int cfg_override = -1) {
+    static const bool dbg_sync = getenv("SSD_HIP_DEBUG_SYNC") != nullptr;
+    if (!dbg_sync) return run_layer_impl(net, l, B, deltas_out, probs_out, st, cfg_override);
+    fprintf(stderr, "[ssd dbg] run %s\n", l.name.c_str());
+    const int rc = run_layer_impl(net, l, B, deltas_out, probs_out, st, cfg_override);
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    (void)hipStreamIsCapturing(st, &cs);
+    if (!rc && cs == hipStreamCaptureStatusNone) SSD_HIP(hipStreamSynchronize(st));
+    return rc;
+}
+
+static int run_layer_impl(ssd_net& net, const Layer& l, int B, float* deltas_out, float* probs_out, hipStream_t st,
+                          int cfg_override) {
     const float* in = l.in >= 0 ? net.tensors[l.in].dev : nullptr;
     float* out = l.out >= 0 ? net.tensors[l.out].dev : nullptr;
     switch (l.kind) {
@@ -546,6 +561,7 @@ static int autotune(ssd_net& net, int B, hipStream_t st) {
         net.splitk_floats = ws_floats;
     }
     int rc = SSD_OK;
+    const bool dbg_sync = getenv("SSD_HIP_DEBUG_SYNC") != nullptr;   // name the launch a GPU fault belongs to
     for (auto& l : net.layers) {
         if (l.kind != LK_CONV) continue;
         const float* in = net.tensors[l.in].dev;
@@ -569,8 +585,10 @@ static int autotune(ssd_net& net, int B, hipStream_t st) {
                 }
                 // min over 3 trials of 4 back-to-back launches: robust against clock ramps / noise
                 const int reps = 4;
+                if (dbg_sync) fprintf(stderr, "[ssd dbg] tune %s %s split %d\n", l.name.c_str(), conv_config_name(c), split);
                 rc = conv_launch(p, c, st);     // warm-up
                 if (rc) break;
+                if (dbg_sync) SSD_HIP(hipStreamSynchronize(st));
                 float ms = 1e30f;
                 for (int trial = 0; trial < 3 && !rc; ++trial) {
                     (void)hipEventRecord(e0, st);
