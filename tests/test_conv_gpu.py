@@ -29,6 +29,18 @@ def _close(a, b, tol=2e-4):
     assert err <= tol * scale, "max abs err %.3e (scale %.3g)" % (err, scale)
 
 
+def guarded(a, pad=4096):
+    """Device copy of `a` in the middle of a NaN-poisoned buffer (pad floats on either side,
+    16-byte alignment kept): an out-of-range read shows up as NaN instead of depending on
+    what the allocator happened to place next to the tensor."""
+    import ssd_hip as h
+    a = np.ascontiguousarray(a, dtype=np.float32)
+    buf = torch.full((a.size + 2 * pad,), float("nan"), dtype=torch.float32, device=h.device())
+    view = buf[pad:pad + a.size].view(a.shape)
+    view.copy_(torch.from_numpy(a))
+    return view
+
+
 def run_conv(x, w, scale=None, shift=None, res=None, stride=1, dil=1, pads=(0, 0, 0, 0), act=0, cfg=-1,
              split_k=1, out_strides=None):
     import ssd_hip as h
@@ -37,7 +49,7 @@ def run_conv(x, w, scale=None, shift=None, res=None, stride=1, dil=1, pads=(0, 0
     kh, kw, _, Cout = w.shape
     d = h.ConvDesc(B, H, W, Cin, Cout, kh, kw, stride, dil, pads[0], pads[2], pads[1], pads[3], act,
                    int(res is not None))
-    xd, wd = h.to_dev(x), h.to_dev(w)
+    xd, wd = guarded(x), h.to_dev(w)
     # the packed weights are followed by NaN poison: a kernel that reads past [Npad][Kpad]
     # (and multiplies by a zero-padded pixel) turns the output NaN
     npk = lib.ssd_conv_packed_weight_floats(kh, kw, Cin, Cout)
@@ -46,9 +58,9 @@ def run_conv(x, w, scale=None, shift=None, res=None, stride=1, dil=1, pads=(0, 0
     h.check(lib.ssd_conv_pack_weights(h.ptr(wd), kh, kw, Cin, Cout, h.ptr(packed), h.stream()), "pack")
     Ho = lib.ssd_conv_out_size(H, kh, stride, dil, pads[0], pads[1])
     Wo = lib.ssd_conv_out_size(W, kw, stride, dil, pads[2], pads[3])
-    sd = h.to_dev(scale) if scale is not None else None
-    hd = h.to_dev(shift) if shift is not None else None
-    rd = h.to_dev(res) if res is not None else None
+    sd = guarded(scale) if scale is not None else None
+    hd = guarded(shift) if shift is not None else None
+    rd = guarded(res) if res is not None else None
     if out_strides is None:
         out = torch.full((B, Ho, Wo, Cout), float("nan"), dtype=torch.float32, device=xd.device)
         bs = ps = 0
@@ -163,7 +175,7 @@ def test_dwconv3x3(H, C, stride):
     else:
         pads = same(H, 3, 1) * 2
     ref = no.relu6(no.depthwise_conv2d(x, w, stride, pads) * scale + shift)
-    xd, wd, sd, hd = h.to_dev(x), h.to_dev(w[..., 0]), h.to_dev(scale), h.to_dev(shift)
+    xd, wd, sd, hd = guarded(x), guarded(w[..., 0]), guarded(scale), guarded(shift)
     out = torch.empty(ref.shape, dtype=torch.float32, device=xd.device)
     h.check(h.lib().ssd_dwconv3x3(h.ptr(xd), B, H, H, C, stride, pads[0], pads[2], pads[1], pads[3], h.ptr(wd),
                                   h.ptr(sd), h.ptr(hd), 2, h.ptr(out), h.stream()), "dw")
@@ -177,7 +189,7 @@ def test_maxpool(H, C, k, stride):
     x = rng.standard_normal((2, H, H, C)).astype(np.float32)
     ref = no.max_pool(x, k, stride)
     a, b = same(H, k, stride)
-    xd = h.to_dev(x)
+    xd = guarded(x)
     out = torch.empty(ref.shape, dtype=torch.float32, device=xd.device)
     h.check(h.lib().ssd_maxpool2d(h.ptr(xd), 2, H, H, C, k, stride, a, a, b, b, h.ptr(out), h.stream()), "pool")
     np.testing.assert_array_equal(_np(out), ref)
@@ -194,7 +206,7 @@ def test_l2norm_and_softmax():
     assert layer.get_config()["scale_factor"] == 20.0
     for rows, L in ((64 * 2268, 21), (1000, 91), (3, 1), (300, 20000)):
         lg = (rng.standard_normal((rows, L)) * 3).astype(np.float32)
-        xd = h.to_dev(lg)
+        xd = guarded(lg)
         out = torch.empty_like(xd)
         h.check(h.lib().ssd_softmax(h.ptr(xd), rows, L, h.ptr(out), h.stream()), "softmax")
         _close(_np(out), no.softmax(lg), 1e-6 if L < 100 else 1e-4)   # sequential fp32 row sum
@@ -430,3 +442,26 @@ def test_conv_bk64_tiles_do_not_read_past_packed_weights():
             _close(_np(out), ref)
             ran += 1
     assert ran > 0
+
+
+@pytest.mark.parametrize("backbone", ["mobilenet_v2", "vgg16"])
+def test_forward_parity_with_poisoned_arena(backbone, monkeypatch):
+    """Every activation surrounded by NaN (SSD_HIP_DEBUG_POISON): no kernel of either graph,
+    fused or layer-by-layer, may read outside its tensors or rely on zeroed scratch."""
+    monkeypatch.setenv("SSD_HIP_DEBUG_POISON", "1")
+    if backbone == "mobilenet_v2":
+        from models.ssd_mobilenet_v2 import get_model
+    else:
+        from models.ssd_vgg16 import get_model
+    hp = helpers.hyper_params(backbone)
+    w = helpers.synthetic_weights(backbone, hp)
+    x = helpers.images(3, 300, seed=11)
+    rd, rp = no.forward(backbone, hp, w, x)
+    for fuse in ((1, 0) if backbone == "mobilenet_v2" else (1,)):
+        m = get_model(hp)
+        m.set_weights(w)
+        m.set_option("fuse_blocks", fuse)
+        d, p = m(x)
+        assert np.isfinite(_np(p)).all() and np.isfinite(_np(d)).all()
+        assert np.abs(_np(p) - rp).max() <= 1e-4
+        _close(_np(d), rd)

@@ -814,15 +814,19 @@ int ssd_net_finalize(ssd_net* net, int max_batch) {
     // activation of the last forward stays inspectable)
     if (net->arena) (void)hipFree(net->arena);
     net->arena = nullptr;
-    size_t total = 0;
-    for (auto& t : net->tensors) total += align_up(t.per_image * max_batch, 64);
+    // SSD_HIP_DEBUG_POISON: NaN-filled arena with a NaN gap around every activation, so a
+    // kernel that reads outside its input (or relies on zero-initialised memory) fails parity
+    const bool poison = getenv("SSD_HIP_DEBUG_POISON") != nullptr;
+    const size_t gap = poison ? 1024 : 0;
+    size_t total = gap;
+    for (auto& t : net->tensors) total += align_up(t.per_image * max_batch, 64) + gap;
     SSD_HIP(hipMalloc((void**)&net->arena, total * sizeof(float)));
-    size_t off = 0;
+    size_t off = gap;
     for (auto& t : net->tensors) {
         t.dev = net->arena + off;
-        off += align_up(t.per_image * max_batch, 64);
+        off += align_up(t.per_image * max_batch, 64) + gap;
     }
-    SSD_HIP(hipMemset(net->arena, 0, total * sizeof(float)));
+    SSD_HIP(hipMemset(net->arena, poison ? 0xFF : 0, total * sizeof(float)));
     net->max_batch = max_batch;
     // pick tile configurations on the device
     for (auto& l : net->layers) { l.cfg = -1; l.split_k = 1; }
