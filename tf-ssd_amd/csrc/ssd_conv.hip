@@ -31,6 +31,14 @@ __device__ __forceinline__ float apply_act(float v, int act) {
     return v;
 }
 
+// Diagnostic builds only (tests/micro/conv_ablate.py): -DSSD_CONV_ABLATE=bits removes one phase
+// of the main loop -- 1 global loads, 2 LDS stores, 4 MFMAs (+ fragment reads), 8 barriers,
+// 16 MFMAs only (fragment reads kept),
+// 64 LDS-only raw barrier.  0 = the production kernel.
+#ifndef SSD_CONV_ABLATE
+#define SSD_CONV_ABLATE 0
+#endif
+
 template <int MT, int NT, int WM, int WN, int BK, bool GEMM1X1>
 __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvParams p) {
     constexpr int BM = 16 * MT * WM, BN = 16 * NT * WN;
@@ -51,27 +59,46 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvParams p) {
     const int HoWo = p.Ho * p.Wo;
 
     // ---- per-thread load bookkeeping (rows are the same for every K tile)
-    const float* xrow[XP];
-    int xiy0[XP], xix0[XP];
-    bool xok[XP];
+    // Addresses are (block base pointer, uniform) + (per-row byte offset, VGPR) + (per-tile byte
+    // offset, SGPR): a load costs an add and a select in the loop.  Lanes whose element is
+    // padding / out of range read offset 0 of the block base (always mapped) and the value is
+    // replaced by zero when the tile is written to LDS -- the loop body has no divergent branch.
+    const int b_first = (int)(m0 / HoWo);
+    const char* xbase = reinterpret_cast<const char*>(p.in + (GEMM1X1 ? m0 * p.Cin : (long)b_first * p.H * p.W * p.Cin));
+    const char* wbase = reinterpret_cast<const char*>(p.w + (long)n0 * p.Kpad);
+    int xoff[XP];              // bytes, relative to xbase (may be negative on padded taps: those are invalid)
+    unsigned xvalid[XP];       // general: bit t = tap t of this row lies inside the image; 1x1: row valid
+    int woff[WP];              // bytes, relative to wbase
+    const float* xrow1[XP];    // 1x1 path: plain row pointers + predicated loads measured faster there
 #pragma unroll
     for (int ps = 0; ps < XP; ++ps) {
         const int u = tid + ps * 256;
         const int row = u / UPR;
         const long m = m0 + row;
-        xok[ps] = (u < XU) && (m < p.M);
-        xiy0[ps] = xix0[ps] = 0;
+        const bool ok = (u < XU) && (m < p.M);
+        xvalid[ps] = 0;
+        xoff[ps] = 0;
         if (GEMM1X1) {
-            xrow[ps] = p.in + (xok[ps] ? m : 0) * p.Cin;
-        } else {
-            const long mm = xok[ps] ? m : 0;
-            const int b = (int)(mm / HoWo);
-            const int pix = (int)(mm - (long)b * HoWo);
+            xvalid[ps] = ok ? 1u : 0u;
+            xrow1[ps] = p.in + (ok ? m : 0) * p.Cin + (tid % UPR) * 4;
+        } else if (ok) {
+            const int b = (int)(m / HoWo);
+            const int pix = (int)(m - (long)b * HoWo);
             const int oy = pix / p.Wo, ox = pix - oy * p.Wo;
-            xiy0[ps] = oy * p.stride - p.pad_t;
-            xix0[ps] = ox * p.stride - p.pad_l;
-            xrow[ps] = p.in + (long)b * p.H * p.W * p.Cin;
+            const int iy0 = oy * p.stride - p.pad_t, ix0 = ox * p.stride - p.pad_l;
+            xoff[ps] = ((((b - b_first) * p.H + iy0) * p.W + ix0) * p.Cin + (tid % UPR) * 4) * 4;
+            for (int ky = 0; ky < p.kh; ++ky)
+                for (int kx = 0; kx < p.kw; ++kx) {
+                    const int iy = iy0 + ky * p.dil, ix = ix0 + kx * p.dil;
+                    if ((unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W) xvalid[ps] |= 1u << (ky * p.kw + kx);
+                }
         }
+    }
+#pragma unroll
+    for (int ps = 0; ps < WP; ++ps) {
+        const int u = tid + ps * 256;
+        const int r = min(u / UPR, min(BN, p.Npad - n0) - 1);     // clamped: rows past the tile / Npad are never used
+        woff[ps] = (r * p.Kpad + (tid % UPR) * 4) * 4;
     }
     const int kq4 = (tid % UPR) * 4;           // identical for every pass (256 % UPR == 0)
 
@@ -83,50 +110,86 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvParams p) {
         kt_end = min(nkt_total, kt_begin + per);
     }
 
-    f32x4 xr[XP], wr[WP];
-    auto load_tile = [&](int kt) {
-        const int k0 = kt * BK;
+    // uniform state of the tile being loaded: k0, its tap (general path) and byte offsets
+    int l_k0 = 0, l_tap = 0, l_ci = 0, l_ky = 0, l_kx = 0, l_xtile = 0;
+    auto tile_setup = [&](int kt) {            // once; afterwards tile_advance()
+        l_k0 = kt * BK;
         if (GEMM1X1) {
-            const int k = k0 + kq4;
-#pragma unroll
-            for (int ps = 0; ps < XP; ++ps) {
-                xr[ps] = f32x4{0.f, 0.f, 0.f, 0.f};
-                if (xok[ps] && k < p.K) xr[ps] = *reinterpret_cast<const f32x4*>(xrow[ps] + k);
-            }
+            l_xtile = l_k0 * 4;
         } else {
-            const int tap = k0 / p.Cin;
-            const int ci = k0 - tap * p.Cin + kq4;
-            const int ky = tap / p.kw, kx = tap - ky * p.kw;
+            l_tap = l_k0 / p.Cin;
+            l_ci = l_k0 - l_tap * p.Cin;
+            l_ky = l_tap / p.kw;
+            l_kx = l_tap - l_ky * p.kw;
+            l_xtile = ((l_ky * p.dil * p.W + l_kx * p.dil) * p.Cin + l_ci) * 4;
+        }
+    };
+    auto tile_advance = [&]() {                // kt -> kt + 1 (Cin % BK == 0 on the general path)
+        l_k0 += BK;
+        if (GEMM1X1) {
+            l_xtile += BK * 4;
+        } else {
+            l_ci += BK;
+            l_xtile += BK * 4;
+            if (l_ci >= p.Cin) {
+                l_ci = 0;
+                ++l_tap;
+                if (++l_kx == p.kw) { l_kx = 0; ++l_ky; }
+                l_xtile = (l_ky * p.dil * p.W + l_kx * p.dil) * p.Cin * 4;
+            }
+        }
+    };
+    auto x_is_valid = [&](int ps) -> bool {
+        if (GEMM1X1) return xvalid[ps] && (l_k0 + kq4 < p.K);
+        return (xvalid[ps] >> l_tap) & 1u;
+    };
+
+    f32x4 xr[XP], wr[WP];
+    auto load_tile = [&]() {                   // the tile described by the l_* state
+        if (SSD_CONV_ABLATE & 1) return;
 #pragma unroll
-            for (int ps = 0; ps < XP; ++ps) {
-                const int iy = xiy0[ps] + ky * p.dil, ix = xix0[ps] + kx * p.dil;
+        for (int ps = 0; ps < XP; ++ps) {
+            if (GEMM1X1) {
                 xr[ps] = f32x4{0.f, 0.f, 0.f, 0.f};
-                if (xok[ps] && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W)
-                    xr[ps] = *reinterpret_cast<const f32x4*>(xrow[ps] + ((long)iy * p.W + ix) * p.Cin + ci);
+                if (x_is_valid(ps)) xr[ps] = *reinterpret_cast<const f32x4*>(xrow1[ps] + l_k0);
+            } else {
+                const int off = x_is_valid(ps) ? xoff[ps] + l_xtile : 0;
+                xr[ps] = *reinterpret_cast<const f32x4*>(xbase + (unsigned)off);     // valid offsets are >= 0: SGPR base + u32 offset
             }
         }
 #pragma unroll
         for (int ps = 0; ps < WP; ++ps) {
-            const int u = tid + ps * 256;
-            const int n = n0 + u / UPR;
-            wr[ps] = f32x4{0.f, 0.f, 0.f, 0.f};
-            if (u < WU && n < p.Npad && k0 + kq4 < p.Kpad)   // BK=64 tiles over a Kpad that is only a multiple of 32
-                wr[ps] = *reinterpret_cast<const f32x4*>(p.w + (long)n * p.Kpad + k0 + kq4);
+            // BK = 64 over a Kpad that is only a multiple of 32: the k >= Kpad half (kq4 >= 32 of
+            // the last tile) re-reads the first half, 128 bytes back (finite values; the matching
+            // X columns are zero) instead of running past the row / the buffer
+            const int koff = (BK <= 32 || l_k0 + kq4 < p.Kpad) ? l_k0 * 4 : -128;
+            if (GEMM1X1 && (SSD_CONV_ABLATE & 256)) {
+                const int u = tid + ps * 256;
+                const int n = n0 + u / UPR;
+                wr[ps] = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (u < WU && n < p.Npad && l_k0 + kq4 < p.Kpad)
+                    wr[ps] = *reinterpret_cast<const f32x4*>(p.w + (long)n * p.Kpad + l_k0 + kq4);
+            } else
+            wr[ps] = *reinterpret_cast<const f32x4*>(wbase + (unsigned)(woff[ps] + koff));
         }
     };
     auto store_tile = [&](int stage) {
+        if (SSD_CONV_ABLATE & 2) return;
         float* Xs = smem + stage * (BM + BN) * LDK;
         float* Ws = Xs + BM * LDK;
 #pragma unroll
         for (int ps = 0; ps < XP; ++ps) {
             const int u = tid + ps * 256;
-            if (u < XU) *reinterpret_cast<f32x4*>(Xs + (u / UPR) * LDK + kq4) = xr[ps];
+            if (XU % 256 == 0 || u < XU)
+                *reinterpret_cast<f32x4*>(Xs + (u / UPR) * LDK + kq4) =
+                    (GEMM1X1 || x_is_valid(ps)) ? xr[ps] : f32x4{0.f, 0.f, 0.f, 0.f};
         }
 #pragma unroll
         for (int ps = 0; ps < WP; ++ps) {
             const int u = tid + ps * 256;
-            if (u < WU) *reinterpret_cast<f32x4*>(Ws + (u / UPR) * LDK + kq4) = wr[ps];
+            if (WU % 256 == 0 || u < WU) *reinterpret_cast<f32x4*>(Ws + (u / UPR) * LDK + kq4) = wr[ps];
         }
+
     };
 
     f32x4 acc[MT][NT];
@@ -137,7 +200,8 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvParams p) {
 
     const int frow = lane & 15, fk = (lane >> 4) * 4;
     if (kt_begin < kt_end) {
-        load_tile(kt_begin);
+        tile_setup(kt_begin);
+        load_tile();
         store_tile(0);
     }
     __syncthreads();
@@ -145,9 +209,13 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvParams p) {
         const int stage = (kt - kt_begin) & 1;
         const float* Xs = smem + stage * (BM + BN) * LDK;
         const float* Ws = Xs + BM * LDK;
-        if (kt + 1 < kt_end) load_tile(kt + 1);
+        const bool more = kt + 1 < kt_end;
+        if (more) {
+            tile_advance();
+            load_tile();
+        }
 #pragma unroll
-        for (int kc = 0; kc < BK / 16; ++kc) {
+        for (int kc = 0; kc < ((SSD_CONV_ABLATE & 4) ? 0 : BK / 16); ++kc) {
             f32x4 a[NT], b[MT];
 #pragma unroll
             for (int ni = 0; ni < NT; ++ni)
@@ -155,6 +223,13 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvParams p) {
 #pragma unroll
             for (int mi = 0; mi < MT; ++mi)
                 b[mi] = *reinterpret_cast<const f32x4*>(Xs + ((wm * MT + mi) * 16 + frow) * LDK + kc * 16 + fk);
+            if (SSD_CONV_ABLATE & 16) {
+#pragma unroll
+                for (int ni = 0; ni < NT; ++ni) asm volatile("" ::"v"(a[ni]));
+#pragma unroll
+                for (int mi = 0; mi < MT; ++mi) asm volatile("" ::"v"(b[mi]));
+                continue;
+            }
 #pragma unroll
             for (int s = 0; s < 4; ++s)
 #pragma unroll
@@ -163,8 +238,9 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvParams p) {
                     for (int ni = 0; ni < NT; ++ni)
                         acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[ni][s], b[mi][s], acc[mi][ni], 0, 0, 0);
         }
-        if (kt + 1 < kt_end) store_tile(stage ^ 1);
-        __syncthreads();
+        if (more) store_tile(stage ^ 1);
+        if (SSD_CONV_ABLATE & 64) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // LDS-only barrier
+        else if (!(SSD_CONV_ABLATE & 8)) __syncthreads();
     }
 
     // ---- epilogue: lane holds out[m = .. + (lane & 15)][n = .. + (lane >> 4) * 4 + 0..3]
@@ -229,25 +305,45 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvParams p) {
     }
 }
 
-// Split-K reduction + epilogue (deterministic order: s = 0, 1, ...).
+// Split-K reduction + epilogue (deterministic order: s = 0, 1, ...).  A thread sums 4
+// consecutive flat [M*Cout] elements with float4 loads (slabs are 16-byte aligned when
+// M*Cout % 4 == 0); the epilogue / scatter to the destination(s) is per element.
+template <int V>
 __global__ void splitk_reduce_kernel(const ConvParams p) {
     const long total = p.M * p.Cout;
+    const long groups = total / V;
     const int HoWo = p.Ho * p.Wo;
-    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
-        const long m = e / p.Cout;
-        const int n = (int)(e - m * p.Cout);
-        float t = 0.f;
-        for (int s = 0; s < p.split_k; ++s) t += p.partial[(long)s * total + e];
-        if (p.scale) t = t * p.scale[n];
-        if (p.shift) t = t + p.shift[n];
-        t = apply_act(t, p.act);
-        if (p.residual) t += p.residual[e];
-        const int b = (int)(m / HoWo);
-        const long pix = m - (long)b * HoWo;
-        if (p.n_split && n >= p.n_split)
-            p.out2[(long)b * p.out2_batch_stride + pix * p.out2_pixel_stride + (n - p.n_split)] = t;
-        else
-            p.out[(long)b * p.out_batch_stride + pix * p.out_pixel_stride + n] = t;
+    for (long g = (long)blockIdx.x * blockDim.x + threadIdx.x; g < groups; g += (long)gridDim.x * blockDim.x) {
+        float t[V];
+#pragma unroll
+        for (int j = 0; j < V; ++j) t[j] = 0.f;
+        for (int s = 0; s < p.split_k; ++s) {
+            const float* src = p.partial + (long)s * total + g * V;
+            if (V == 4) {
+                const f32x4 v = *reinterpret_cast<const f32x4*>(src);
+#pragma unroll
+                for (int j = 0; j < V; ++j) t[j] += v[j];
+            } else {
+                t[0] += src[0];
+            }
+        }
+        long m = (g * V) / p.Cout;
+        int n = (int)(g * V - m * p.Cout);
+#pragma unroll
+        for (int j = 0; j < V; ++j) {
+            float r = t[j];
+            if (p.scale) r = r * p.scale[n];
+            if (p.shift) r = r + p.shift[n];
+            r = apply_act(r, p.act);
+            if (p.residual) r += p.residual[g * V + j];
+            const int b = (int)(m / HoWo);
+            const long pix = m - (long)b * HoWo;
+            if (p.n_split && n >= p.n_split)
+                p.out2[(long)b * p.out2_batch_stride + pix * p.out2_pixel_stride + (n - p.n_split)] = r;
+            else
+                p.out[(long)b * p.out_batch_stride + pix * p.out_pixel_stride + n] = r;
+            if (++n == p.Cout) { n = 0; ++m; }
+        }
     }
 }
 
@@ -475,6 +571,7 @@ bool conv_config_valid(int cfg, const ConvParams& p) {
     if (((uintptr_t)p.in & 15) || ((uintptr_t)p.w & 15)) return false;
     if (p.Cin % 4) return false;
     if (is_gemm1x1(p)) return true;
+    if (p.kh * p.kw > 32) return false;          // per-row tap validity is a 32-bit mask
     return p.Cin % kCfgs[cfg].BK == 0;
 }
 
@@ -547,8 +644,11 @@ int conv_launch(const ConvParams& p, int cfg, hipStream_t st) {
     SSD_LAUNCH_CHECK();
     if (p.split_k > 1) {
         const long total = p.M * p.Cout;
-        const int blocks = (int)(cdiv(total, 256) < 4096 ? cdiv(total, 256) : 4096);
-        hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, st, p);
+        const bool vec = (total % 4 == 0) && (((uintptr_t)p.partial & 15) == 0);
+        const long groups = vec ? total / 4 : total;
+        const int blocks = (int)(cdiv(groups, 256) < 8192 ? cdiv(groups, 256) : 8192);
+        if (vec) hipLaunchKernelGGL(splitk_reduce_kernel<4>, dim3(blocks), dim3(256), 0, st, p);
+        else hipLaunchKernelGGL(splitk_reduce_kernel<1>, dim3(blocks), dim3(256), 0, st, p);
         SSD_LAUNCH_CHECK();
     }
     return SSD_OK;

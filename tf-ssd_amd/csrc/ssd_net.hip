@@ -546,13 +546,16 @@ static int autotune(ssd_net& net, int B, hipStream_t st) {
     float *d = nullptr, *pr = nullptr;     // scratch outputs for the head convs
     SSD_HIP(hipMalloc((void**)&d, (size_t)B * net.num_priors * 4 * sizeof(float)));
     SSD_HIP(hipMalloc((void**)&pr, (size_t)B * net.num_priors * net.L * sizeof(float)));
-    static const int kSplits[] = {1, 2, 4, 8, 16};
+    // dense around small factors: the best split is the one whose M-blocks x split just fills a
+    // whole number of CU rounds (e.g. 100 M-blocks x 5 = 500 blocks on 512 slots for head 2)
+    static const int kSplits[] = {1, 2, 3, 4, 5, 6, 7, 8, 10, 12, 14, 16, 20, 24, 32};
+    constexpr int kNumSplits = sizeof(kSplits) / sizeof(kSplits[0]);
     // split-K workspace: the largest [split][M][Cout] slab any candidate may need
     size_t ws_floats = 0;
     for (auto& l : net.layers) {
         if (l.kind != LK_CONV) continue;
         const size_t mc = (size_t)B * l.Ho * l.Wo * l.Cout;
-        if (mc <= (size_t)4 << 20) ws_floats = std::max(ws_floats, mc * 16);
+        if (mc <= (size_t)4 << 20) ws_floats = std::max(ws_floats, mc * 32);
     }
     if (ws_floats > net.splitk_floats) {
         if (net.splitk_ws) (void)hipFree(net.splitk_ws);
@@ -570,7 +573,7 @@ static int autotune(ssd_net& net, int B, hipStream_t st) {
         float best = 1e30f;
         int best_cfg = -1, best_split = 1;
         for (int c = 0; c < conv_num_configs() && !rc; ++c) {
-            for (int si = 0; si < 5 && !rc; ++si) {
+            for (int si = 0; si < kNumSplits && !rc; ++si) {
                 const int split = kSplits[si];
                 l.split_k = split;
                 ConvParams p = layer_conv_params(net, l, B, in, out, res, d, pr);

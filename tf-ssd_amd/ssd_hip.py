@@ -11,7 +11,7 @@ import numpy as np
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libssd_hip.so")
+LIB_PATH = os.environ.get("SSD_HIP_LIBRARY") or os.path.join(_HERE, "libssd_hip.so")   # override: diagnostic builds
 
 c_float_p = ctypes.POINTER(ctypes.c_float)
 c_int_p = ctypes.POINTER(ctypes.c_int)
