@@ -116,7 +116,7 @@ assert torch.equal(s[:, 2], torch.arange(n, dtype=torch.float32) + 200)
 assert parallel.max_over_ranks(1.0 + rank) == 2.0
 torch.distributed.barrier()
 torch.distributed.destroy_process_group()
-print("rank", rank, "ok")
+sys.stdout.write("rank " + str(rank) + " ok\n"); sys.stdout.flush()
 '''
 
 
