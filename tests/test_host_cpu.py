@@ -133,3 +133,40 @@ def test_two_process_gloo_gather(tmp_path):
                          env=env, capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "rank 0 ok" in out.stdout and "rank 1 ok" in out.stdout
+
+
+# ---------------------------------------------------------------------------------------------
+# Graph builder of the native library (host-only code: no GPU needed) against the oracle's
+# parameter table and against PUBLISHED known answers for the two backbones -- the only
+# external anchors available offline (the reference has no tests / fixtures):
+#   * keras.applications.MobileNetV2(include_top=False, alpha=1.0).summary():
+#       Total params 2,257,984 / trainable 2,223,872 / non-trainable 34,112
+#   * keras.applications.VGG16(include_top=False).summary(): Total params 14,714,688
+#   * SSD300 (Liu et al. 2016) VGG16 head: 8732 default boxes; the reference's MobileNetV2
+#     feature maps [19,10,5,3,2,1] with the same aspect ratios give 2268
+#     (utils/train_utils.py:12-33, utils/bbox_utils.py:139-158).
+@pytest.mark.parametrize("backbone,n_priors", [("mobilenet_v2", 2268), ("vgg16", 8732)])
+def test_native_graph_matches_oracle_and_published_counts(backbone, n_priors):
+    import numpy as np
+    import helpers
+    from oracle import net_oracle as no
+    from models._net import SSDModel
+    hp = helpers.hyper_params(backbone)
+    m = SSDModel(backbone, hp)                      # ssd_net_create only: host code
+    assert m.param_specs == no.param_specs(backbone, hp)
+    assert m.num_priors == n_priors
+    names = [n for n, _ in m.param_specs]
+    count = lambda specs: sum(int(np.prod(s)) for _, s in specs)
+    if backbone == "mobilenet_v2":
+        back = m.param_specs[:names.index("Conv_1_bn/moving_variance") + 1]
+        assert count(back) == 2257984
+        assert count([(n, s) for n, s in back if "moving_" in n]) == 34112
+        assert count(back) - 34112 == 2223872
+    else:
+        back = m.param_specs[:names.index("conv5_3/bias") + 1]
+        assert count(back) == 14714688
+    # a hyper-parameter set that does not describe this graph is refused
+    bad = dict(hp)
+    bad["feature_map_shapes"] = list(hp["feature_map_shapes"][:-1]) + [7]
+    with pytest.raises(ValueError):
+        SSDModel(backbone, bad)
