@@ -11,10 +11,10 @@ cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 CMD="python bench.py --steps 10 --warmup 3 --no-cpu-baseline"
 # first run only fills the tuning cache, so that the profiled runs contain no autotune launches
 export SSD_HIP_TUNE_CACHE=$OUT/tune
-$CMD > $OUT/bench_plain.log 2>&1
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o t -- $CMD > $OUT/bench_trace.log 2>&1
-rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch -o f -- $CMD > $OUT/bench_fetch.log 2>&1
-rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write -o w -- $CMD > $OUT/bench_write.log 2>&1
+timeout 600 $CMD > $OUT/bench_plain.log 2>&1
+timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o t -- $CMD > $OUT/bench_trace.log 2>&1
+timeout 900 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch -o f -- $CMD > $OUT/bench_fetch.log 2>&1
+timeout 900 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write -o w -- $CMD > $OUT/bench_write.log 2>&1
 find $OUT -name "*.csv" | head -20
 python profiles/summarize.py $OUT > $OUT/summary.txt 2>&1
 tail -60 $OUT/summary.txt
