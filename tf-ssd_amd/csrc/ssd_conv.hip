@@ -63,7 +63,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvParams p) {
     // offset, SGPR): a load costs an add and a select in the loop.  Lanes whose element is
     // padding / out of range read offset 0 of the block base (always mapped) and the value is
     // replaced by zero when the tile is written to LDS -- the loop body has no divergent branch.
-    const int b_first = (int)(m0 / HoWo);
+    const int b_first = (int)m0 / HoWo;
     const char* xbase = reinterpret_cast<const char*>(p.in + (GEMM1X1 ? m0 * p.Cin : (long)b_first * p.H * p.W * p.Cin));
     const char* wbase = reinterpret_cast<const char*>(p.w + (long)n0 * p.Kpad);
     int xoff[XP];              // bytes, relative to xbase (may be negative on padded taps: those are invalid)
@@ -82,8 +82,8 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvParams p) {
             xvalid[ps] = ok ? 1u : 0u;
             xrow1[ps] = p.in + (ok ? m : 0) * p.Cin + (tid % UPR) * 4;
         } else if (ok) {
-            const int b = (int)(m / HoWo);
-            const int pix = (int)(m - (long)b * HoWo);
+            const int b = (int)m / HoWo;              // M < 2^31 (host check)
+            const int pix = (int)m - b * HoWo;
             const int oy = pix / p.Wo, ox = pix - oy * p.Wo;
             const int iy0 = oy * p.stride - p.pad_t, ix0 = ox * p.stride - p.pad_l;
             xoff[ps] = ((((b - b_first) * p.H + iy0) * p.W + ix0) * p.Cin + (tid % UPR) * 4) * 4;
@@ -244,45 +244,82 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvParams p) {
     }
 
     // ---- epilogue: lane holds out[m = .. + (lane & 15)][n = .. + (lane >> 4) * 4 + 0..3]
+    // (M < 2^31 is checked on the host: 32-bit index arithmetic)
+    if (p.split_k > 1) {           // partial sums only; scale/shift/act/residual happen in the reduce
+#pragma unroll
+        for (int mi = 0; mi < MT; ++mi) {
+            const int m = (int)m0 + (wm * MT + mi) * 16 + (lane & 15);
+            if (m >= (int)p.M) continue;
+#pragma unroll
+            for (int ni = 0; ni < NT; ++ni) {
+                const int n = n0 + (wn * NT + ni) * 16 + (lane >> 4) * 4;
+                if (n >= p.Cout) continue;
+                float* prow = p.partial + ((long)blockIdx.y * p.M + m) * p.Cout + n;
+                if (n + 3 < p.Cout && (p.Cout & 3) == 0) {
+                    *reinterpret_cast<f32x4*>(prow) = acc[mi][ni];
+                } else {
+                    for (int j = 0; j < 4; ++j)
+                        if (n + j < p.Cout) prow[j] = acc[mi][ni][j];
+                }
+            }
+        }
+        return;
+    }
+    // All loads of the epilogue are issued first (scale/shift per column group, residual per
+    // tile), the stores follow back to back: a load between two stores costs a full store
+    // round trip on gfx950 (vmcnt counts stores and the waits are not selective).
+    f32x4 sc[NT], sh[NT];
+    bool vecn[NT];
+#pragma unroll
+    for (int ni = 0; ni < NT; ++ni) {
+        const int n = n0 + (wn * NT + ni) * 16 + (lane >> 4) * 4;
+        const bool straddle = p.n_split && n < p.n_split && n + 3 >= p.n_split;
+        vecn[ni] = (n + 3 < p.Cout) && !straddle;
+        sc[ni] = f32x4{1.f, 1.f, 1.f, 1.f};
+        sh[ni] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (vecn[ni]) {
+            if (p.scale) sc[ni] = *reinterpret_cast<const f32x4*>(p.scale + n);
+            if (p.shift) sh[ni] = *reinterpret_cast<const f32x4*>(p.shift + n);
+        }
+    }
+    const bool res_vec = p.residual && (p.Cout & 3) == 0;
+    f32x4 rs[MT][NT];
+    if (res_vec) {
+#pragma unroll
+        for (int mi = 0; mi < MT; ++mi) {
+            const int m = (int)m0 + (wm * MT + mi) * 16 + (lane & 15);
+#pragma unroll
+            for (int ni = 0; ni < NT; ++ni) {
+                const int n = n0 + (wn * NT + ni) * 16 + (lane >> 4) * 4;
+                rs[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (m < (int)p.M && vecn[ni]) rs[mi][ni] = *reinterpret_cast<const f32x4*>(p.residual + (long)m * p.Cout + n);
+            }
+        }
+    }
 #pragma unroll
     for (int mi = 0; mi < MT; ++mi) {
-        const long m = m0 + (wm * MT + mi) * 16 + (lane & 15);
-        if (m >= p.M) continue;
-        const int b = (int)(m / HoWo);
-        const long pix = m - (long)b * HoWo;
-        float* orow = p.out + (long)b * p.out_batch_stride + pix * p.out_pixel_stride;
-        float* orow2 = p.n_split ? p.out2 + (long)b * p.out2_batch_stride + pix * p.out2_pixel_stride - p.n_split : nullptr;
+        const int m = (int)m0 + (wm * MT + mi) * 16 + (lane & 15);
+        if (m >= (int)p.M) continue;
+        const int b = m / HoWo;
+        const int pix = m - b * HoWo;
+        float* orow = p.out + (long)b * p.out_batch_stride + (long)pix * p.out_pixel_stride;
+        float* orow2 = p.n_split ? p.out2 + (long)b * p.out2_batch_stride + (long)pix * p.out2_pixel_stride - p.n_split : nullptr;
 #pragma unroll
         for (int ni = 0; ni < NT; ++ni) {
             const int n = n0 + (wn * NT + ni) * 16 + (lane >> 4) * 4;
             if (n >= p.Cout) continue;
             f32x4 v = acc[mi][ni];
-            if (p.split_k > 1) {
-                float* prow = p.partial + ((long)blockIdx.y * p.M + m) * p.Cout + n;
-                if (n + 3 < p.Cout && (p.Cout & 3) == 0) {
-                    *reinterpret_cast<f32x4*>(prow) = v;
-                } else {
-                    for (int j = 0; j < 4; ++j)
-                        if (n + j < p.Cout) prow[j] = v[j];
-                }
-                continue;
-            }
-            const bool full = n + 3 < p.Cout;
-            const bool side2 = p.n_split && n >= p.n_split;
-            const bool straddle = p.n_split && n < p.n_split && n + 3 >= p.n_split;
-            if (full && !straddle) {
-                if (p.scale) v = v * *reinterpret_cast<const f32x4*>(p.scale + n);
-                if (p.shift) v = v + *reinterpret_cast<const f32x4*>(p.shift + n);
+            if (vecn[ni]) {
+                v = v * sc[ni] + sh[ni];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) v[j] = apply_act(v[j], p.act);
-                if (p.residual) {
-                    const float* rr = p.residual + m * p.Cout + n;
-                    if ((p.Cout & 3) == 0) {
-                        v = v + *reinterpret_cast<const f32x4*>(rr);
-                    } else {
-                        for (int j = 0; j < 4; ++j) v[j] += rr[j];
-                    }
+                if (res_vec) {
+                    v = v + rs[mi][ni];
+                } else if (p.residual) {
+                    const float* rr = p.residual + (long)m * p.Cout + n;
+                    for (int j = 0; j < 4; ++j) v[j] += rr[j];
                 }
+                const bool side2 = p.n_split && n >= p.n_split;
                 float* dst = (side2 ? orow2 : orow) + n;
                 if ((side2 ? p.vec_store2 : p.vec_store) && ((((uintptr_t)dst) & 15) == 0)) {
                     *reinterpret_cast<f32x4*>(dst) = v;
@@ -296,7 +333,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvParams p) {
                     if (p.scale) t = t * p.scale[n + j];
                     if (p.shift) t = t + p.shift[n + j];
                     t = apply_act(t, p.act);
-                    if (p.residual) t += p.residual[m * p.Cout + n + j];
+                    if (p.residual) t += p.residual[(long)m * p.Cout + n + j];
                     float* drow = (p.n_split && n + j >= p.n_split) ? orow2 : orow;
                     drow[n + j] = t;
                 }
@@ -570,6 +607,7 @@ bool conv_config_valid(int cfg, const ConvParams& p) {
     if (cfg < 0 || cfg >= kNumMfmaCfgs) return false;
     if (((uintptr_t)p.in & 15) || ((uintptr_t)p.w & 15)) return false;
     if (p.Cin % 4) return false;
+    if (p.M > 0x7fffffffL - 1024) return false;   // 32-bit pixel indices in the kernel
     if (is_gemm1x1(p)) return true;
     if (p.kh * p.kw > 32) return false;          // per-row tap validity is a 32-bit mask
     return p.Cin % kCfgs[cfg].BK == 0;
