@@ -227,7 +227,9 @@ double ssd_net_layer_bytes(const ssd_net* net, int i, int B); /* in + out + weig
  * (keyed by the pointers/sizes of the call; streams other than the NULL stream only);
  * "fuse_blocks" (default 1) runs eligible MobileNetV2 inverted-residual blocks
  * (expand -> depthwise -> project) as one fused kernel; 0 runs them as three layers (then
- * every intermediate activation is inspectable). */
+ * every intermediate activation is inspectable); "fuse_dwproj" (default 1, needs fuse_blocks)
+ * runs depthwise -> project of the remaining blocks (7-16) as one kernel behind the expand
+ * GEMM; "overlap_heads" (default 1) runs the SSD head convs on a side stream. */
 int ssd_net_set_option(ssd_net* net, const char* name, int value);
 /* Diagnostics: per-phase mean cycles per wave of one fused block layer (clock64 inside the
  * kernel): prologue, expand, depthwise, project, weight staging, epilogue. */

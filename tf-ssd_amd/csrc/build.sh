@@ -21,7 +21,7 @@ compile() {  # src extra-flags
 # box math: separately-rounded fp32 ops (bit-exact indices vs the oracle)
 compile ssd_core.hip
 compile ssd_bbox.hip -ffp-contract=off -fhip-fp32-correctly-rounded-divide-sqrt
-for s in ssd_conv.hip ssd_ops.hip ssd_fused.hip ssd_net.hip; do
+for s in ssd_conv.hip ssd_ops.hip ssd_fused.hip ssd_dwproj.hip ssd_net.hip; do
   [ -f "$s" ] && compile "$s"
 done
 if [ $need_link = 1 ] || [ ! -f $OUT ]; then

@@ -61,6 +61,22 @@ struct StemParams {
     int B, H, W, H1, W1, pad_t, pad_l, kpad1, kpadp;
     int tiles_y, tiles_x;
 };
+// Depthwise 3x3 + BN + ReLU6 -> project 1x1 + BN (+ residual) of one MobileNetV2 block
+// (csrc/ssd_dwproj.hip); BN scales are folded into wd / wp by the caller.
+struct DwProjParams {
+    const float* e;             // expanded activations [B,H,W,Ce] (after expand BN + ReLU6)
+    const float* wd;            // depthwise weights [9][Ce], BN scale folded in
+    const float* dh;            // depthwise BN shift [Ce]
+    const float* wp;            // project weights packed [npad_p][kpad_p], BN scale folded in
+    const float* ph;            // project BN shift [Cout]
+    const float* res;           // residual [B,Ho,Wo,Cout] or nullptr
+    float* y;                   // [B,Ho,Wo,Cout]
+    int B, H, W, Ce, Cout, Ho, Wo, stride, pad_t, pad_l;
+    int kpad_p, npad_p;
+    int tiles_y, tiles_x;       // filled by the launcher
+};
+bool dwproj_supported(const DwProjParams& p);
+int launch_dwproj(DwProjParams p, hipStream_t st);
 bool stem_supported(const StemParams& p);
 int launch_stem(StemParams p, hipStream_t st);
 bool fused_block_supported(const FusedBlockParams& p);

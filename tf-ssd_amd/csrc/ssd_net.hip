@@ -58,8 +58,10 @@ struct Layer {
     // fused inverted-residual block: LK_FUSED layer points at its three member layers;
     // members carry the index of their LK_FUSED layer in `fused_by`
     int f_expand = -1, f_dw = -1, f_project = -1;
-    int f_type = 0;                 // 0: inverted-residual block, 1: stem (Conv1 -> dw -> project)
+    int f_type = 0;                 // 0: inverted-residual block, 1: stem (Conv1 -> dw -> project),
+                                    // 2: depthwise + project (the expand conv stays a GEMM of its own)
     int fused_by = -1;
+    int fused_by2 = -1;             // depthwise / project members: their type-2 LK_FUSED layer
     float* splitk_part = nullptr;   // this layer's own split-K slab (layers may run concurrently)
     // LK_FUSED: weight copies with the folded BatchNorm scale multiplied in (per output channel)
     float *fz_we = nullptr, *fz_wd = nullptr, *fz_wp = nullptr;
@@ -84,6 +86,7 @@ struct ssd_net {
     int num_priors = 0;
     bool finalized = false;
     bool fuse_blocks = true;        // run eligible inverted-residual blocks as one fused kernel
+    bool fuse_dwproj = true;        // ... and depthwise + project of the others as one kernel
     int max_batch = 0;
     int last_batch = 0;
     std::vector<float*> owned;      // device allocations to free
@@ -334,21 +337,42 @@ static void build_mobilenet_v2(ssd_net& net) {
         const bool res = (cin == cout && s == 1);
         x = b.conv(p + "project", p + "out", x, cout, 1, 1, 1, 1, p + "project_BN", false, SSD_ACT_NONE,
                    res ? inp : -1);
+        int ie = (int)net.layers.size() - 3;      // expand, depthwise = ie + 1, project = ie + 2
         if (k != 13) {      // block 13's expanded map is SSD feature map #1: it must reach HBM
-            const int n = (int)net.layers.size();
             Layer f;
             f.name = p + "fused";
             f.kind = LK_FUSED;
-            f.f_expand = n - 3; f.f_dw = n - 2; f.f_project = n - 1;
             f.in = inp; f.out = x;
-            const Layer& le = net.layers[n - 3];
-            const Layer& ld = net.layers[n - 2];
+            const Layer& le = net.layers[ie];
+            const Layer& ld = net.layers[ie + 1];
             f.H = le.H; f.W = le.W; f.Cin = le.Cin; f.Ho = ld.Ho; f.Wo = ld.Wo; f.Cout = cout;
             f.stride = s; f.pt = ld.pt; f.pl = ld.pl;
-            net.layers.insert(net.layers.end() - 3, f);       // fused layer runs first, members follow
-            const int fi = n - 3;
-            net.layers[fi].f_expand = fi + 1; net.layers[fi].f_dw = fi + 2; net.layers[fi].f_project = fi + 3;
-            for (int j = 1; j <= 3; ++j) net.layers[fi + j].fused_by = fi;
+            net.layers.insert(net.layers.begin() + ie, f);    // fused layer runs first, members follow
+            const int fi = ie;
+            ++ie;
+            net.layers[fi].f_expand = ie; net.layers[fi].f_dw = ie + 1; net.layers[fi].f_project = ie + 2;
+            for (int j = 0; j < 3; ++j) net.layers[ie + j].fused_by = fi;
+        }
+        {   // depthwise + project as one kernel behind the expand GEMM (used when the whole-block
+            // kernel above does not take the shape: Cin > 32, and for block 13)
+            Layer f;
+            f.name = p + "dwproj";
+            f.kind = LK_FUSED;
+            f.f_type = 2;
+            const Layer& ld = net.layers[ie + 1];
+            f.in = ld.in; f.out = x;
+            f.H = ld.H; f.W = ld.W; f.Cin = ld.Cin; f.Ho = ld.Ho; f.Wo = ld.Wo; f.Cout = cout;
+            f.stride = s; f.pt = ld.pt; f.pl = ld.pl;
+            net.layers.insert(net.layers.begin() + ie + 1, f);
+            const int fi = ie + 1;
+            net.layers[fi].f_dw = fi + 1; net.layers[fi].f_project = fi + 2;
+            net.layers[fi].fused_by = net.layers[ie].fused_by;     // a whole-block kernel covers it too
+            if (net.layers[fi].fused_by >= 0) {                     // member indices of the block layer moved by one
+                Layer& blk = net.layers[net.layers[fi].fused_by];
+                blk.f_dw = fi + 1; blk.f_project = fi + 2;
+            }
+            net.layers[fi + 1].fused_by2 = fi;
+            net.layers[fi + 2].fused_by2 = fi;
         }
         cin = cout;
     }
@@ -459,6 +483,22 @@ static FusedBlockParams fused_params(const ssd_net& net, const Layer& f, int B) 
     return p;
 }
 
+static DwProjParams dwproj_params(const ssd_net& net, const Layer& f, int B) {
+    const Layer& ld = net.layers[f.f_dw];
+    const Layer& lp = net.layers[f.f_project];
+    DwProjParams p{};
+    p.e = net.tensors[f.in].dev;
+    p.y = net.tensors[f.out].dev;
+    p.wd = f.fz_wd; p.dh = ld.shift;
+    p.wp = f.fz_wp; p.ph = lp.shift;
+    p.res = lp.res >= 0 ? net.tensors[lp.res].dev : nullptr;
+    p.B = B; p.H = f.H; p.W = f.W; p.Ce = ld.Cout; p.Cout = f.Cout;
+    p.Ho = f.Ho; p.Wo = f.Wo; p.stride = f.stride; p.pad_t = f.pt; p.pad_l = f.pl;
+    p.kpad_p = conv_kpad(lp.Cin);
+    p.npad_p = conv_npad(lp.Cout);
+    return p;
+}
+
 static StemParams stem_params(const ssd_net& net, const Layer& f, int B) {
     const Layer& l1 = net.layers[f.f_expand];
     const Layer& ld = net.layers[f.f_dw];
@@ -511,6 +551,7 @@ static int run_layer_impl(ssd_net& net, const Layer& l, int B, float* deltas_out
             return launch_softmax(probs_out, (long)B * net.num_priors, net.L, probs_out, st);
         case LK_FUSED:
             if (l.f_type == 1) return launch_stem(stem_params(net, l, B), st);
+            if (l.f_type == 2) return launch_dwproj(dwproj_params(net, l, B), st);
             return launch_fused_block(fused_params(net, l, B), st);
     }
     return SSD_OK;
@@ -521,11 +562,17 @@ static int run_layer_impl(ssd_net& net, const Layer& l, int B, float* deltas_out
 static bool fused_active(const ssd_net& net, const Layer& f) {
     if (!net.fuse_blocks) return false;
     if (f.f_type == 1) return stem_supported(stem_params(net, f, 1));
+    if (f.f_type == 2) {
+        if (!net.fuse_dwproj) return false;
+        if (f.fused_by >= 0 && fused_active(net, net.layers[f.fused_by])) return false;   // whole block fused
+        return dwproj_supported(dwproj_params(net, f, 1));
+    }
     return fused_block_supported(fused_params(net, f, 1));
 }
 static bool layer_runs(const ssd_net& net, const Layer& l) {
     if (l.kind == LK_FUSED) return fused_active(net, l);
-    if (l.fused_by >= 0) return !fused_active(net, net.layers[l.fused_by]);
+    if (l.fused_by >= 0 && fused_active(net, net.layers[l.fused_by])) return false;
+    if (l.fused_by2 >= 0 && fused_active(net, net.layers[l.fused_by2])) return false;
     return true;
 }
 
@@ -797,6 +844,18 @@ int ssd_net_finalize(ssd_net* net, int max_batch) {
     }
     // fused blocks: weight copies with the BatchNorm scale folded in
     for (auto& f : net->layers) {
+        if (f.kind == LK_FUSED && f.f_type == 2) {
+            const Layer& ld = net->layers[f.f_dw];
+            const Layer& lp = net->layers[f.f_project];
+            const size_t nd = (size_t)9 * ld.Cout, np = (size_t)conv_kpad(lp.Cin) * conv_npad(lp.Cout);
+            int rc = dev_alloc(*net, nd, &f.fz_wd);
+            if (!rc) rc = dev_alloc(*net, np, &f.fz_wp);
+            if (rc) return rc;
+            rc = launch_scale_cols(net->params[ld.p_kernel].dev, ld.scale, 9, ld.Cout, f.fz_wd, st);
+            if (!rc) rc = launch_scale_rows(lp.packed, lp.scale, conv_npad(lp.Cout), lp.Cout, conv_kpad(lp.Cin), f.fz_wp, st);
+            if (rc) return rc;
+            continue;
+        }
         if (f.kind != LK_FUSED || f.f_type != 0) continue;
         const Layer& le = net->layers[f.f_expand];
         const Layer& ld = net->layers[f.f_dw];
@@ -1101,6 +1160,11 @@ int ssd_net_set_option(ssd_net* net, const char* name, int value) {
     SSD_CHECK_ARG(net && name, "ssd_net_set_option: NULL argument");
     if (std::string(name) == "fuse_blocks") {
         net->fuse_blocks = value != 0;
+        net->drop_graphs();
+        return SSD_OK;
+    }
+    if (std::string(name) == "fuse_dwproj") {
+        net->fuse_dwproj = value != 0;
         net->drop_graphs();
         return SSD_OK;
     }
