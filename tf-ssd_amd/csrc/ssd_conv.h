@@ -74,6 +74,7 @@ struct DwProjParams {
     int B, H, W, Ce, Cout, Ho, Wo, stride, pad_t, pad_l;
     int kpad_p, npad_p;
     int tiles_y, tiles_x;       // filled by the launcher
+    int ablate;                 // diagnostics (SSD_DWPROJ_ABLATE): 1 skip depthwise math, 2 skip MFMAs, 4 skip chunk loads
 };
 bool dwproj_supported(const DwProjParams& p);
 int launch_dwproj(DwProjParams p, hipStream_t st);

@@ -160,9 +160,9 @@ __global__ __launch_bounds__(256) void dwproj_kernel(const DwProjParams p) {
     lds_barrier();
     for (int c = 0; c < nchunks; ++c) {
         const bool more = c + 1 < nchunks;
-        if (more) load_chunk((c + 1) * kCK);
+        if (more && !(p.ablate & 4)) load_chunk((c + 1) * kCK);
         // ---- B: depthwise 3x3 + shift + ReLU6 -> Ds
-        if (dw_on) {
+        if (dw_on && !(p.ablate & 1)) {
             f32x4 o[SL];
             const f32x4 sh = *reinterpret_cast<const f32x4*>(Wd + 9 * kCK + cq * 4);
 #pragma unroll
@@ -194,7 +194,7 @@ __global__ __launch_bounds__(256) void dwproj_kernel(const DwProjParams p) {
         lds_barrier();
         // ---- C: project on the MFMA (weights = A operand, pixels = B operand)
 #pragma unroll
-        for (int kc = 0; kc < kCK / 16; ++kc) {
+        for (int kc = 0; kc < ((p.ablate & 2) ? 0 : kCK / 16); ++kc) {
             f32x4 a[NTW], bb[MTW];
 #pragma unroll
             for (int ni = 0; ni < NTW; ++ni)
@@ -211,7 +211,7 @@ __global__ __launch_bounds__(256) void dwproj_kernel(const DwProjParams p) {
                         acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[ni][s], bb[mi][s], acc[mi][ni], 0, 0, 0);
         }
         lds_barrier();
-        if (more) {
+        if (more && !(p.ablate & 4)) {
             store_chunk();
             lds_barrier();
         }
@@ -242,15 +242,227 @@ __global__ __launch_bounds__(256) void dwproj_kernel(const DwProjParams p) {
     }
 }
 
+// 8-wave variant: waves 0-3 ("producers") stage chunks and run the depthwise, waves 4-7
+// ("consumers") run the project MFMAs of the previous chunk at the same time; E / D / Wp / Wd
+// tiles are double-buffered in LDS and one workgroup barrier per chunk hands them over.
+// At the start of iteration i:   Ds[i&1] = D(i),  Ws[i&1] = Wp(i),  Es/Wd[(i+1)&1] = E/wd(i+1),
+// producer registers hold the in-flight loads of E/wd(i+2) and Wp(i+1).
+//   producers, iteration i:  depthwise(i+1): Es[(i+1)&1] -> Ds[(i+1)&1];
+//                            registers -> Es/Wd[i&1] (E/wd(i+2)), Ws[(i+1)&1] (Wp(i+1));
+//                            issue loads of E/wd(i+3), Wp(i+2)
+//   consumers, iteration i:  acc += Ds[i&1] x Ws[i&1]
+// (a phase ablation of the 4-wave kernel showed its depthwise, MFMA and staging times simply add
+// up: 6.4 + 8.5 + 4.3 us of a 33 us block_7 launch, 10.9 + 20.4 + 9.7 of 55 us for block_11.)
+template <int S, int TH, int TW, int SL, int WM, int WN, int NTW>
+__global__ __launch_bounds__(512) void dwproj8_kernel(const DwProjParams p) {
+    using Sh = DwProjShape<S, TH, TW, SL, WM, WN, NTW>;
+    constexpr int PT = Sh::PT, PG = Sh::PG, MTW = Sh::MTW, NTB = Sh::NTB, IW = Sh::IW, HP = Sh::HP;
+    constexpr int ES = HP * kLD, DS = PG * 16 * kLD, WS = NTB * 16 * kLD, WD = 10 * kCK;
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    float* Es = sm;                  // [2][HP][kLD]
+    float* Ds = Es + 2 * ES;         // [2][PG*16][kLD]
+    float* Ws = Ds + 2 * DS;         // [2][NTB*16][kLD]
+    float* Wd = Ws + 2 * WS;         // [2][10][kCK]
+
+    const int tid = threadIdx.x & 255, lane = threadIdx.x & 63, wave = (threadIdx.x >> 6) & 3;
+    const bool producer = threadIdx.x < 256;
+    const int wm = wave / WN, wn = wave % WN;
+    const int tiles_per_img = p.tiles_y * p.tiles_x;
+    const int b = blockIdx.x / tiles_per_img;
+    const int rem = blockIdx.x - b * tiles_per_img;
+    const int ty = rem / p.tiles_x, tx = rem - ty * p.tiles_x;
+    const int oy0 = ty * TH, ox0 = tx * TW;
+    const int iy0 = oy0 * S - p.pad_t, ix0 = ox0 * S - p.pad_l;
+    const int nt0 = blockIdx.y * NTB;
+    const float* eb = p.e + (long)b * p.H * p.W * p.Ce;
+    const int nchunks = p.Ce / kCK;
+
+    if (producer) {
+        const int cq = tid % kCQ, strip = tid / kCQ;
+        const bool dw_on = strip < Sh::STRIPS;
+        const int sr = strip / Sh::NSX, sx0 = (strip - sr * Sh::NSX) * SL;
+        constexpr int E_U = HP * kCQ, W_U = NTB * 16 * kCQ;
+        constexpr int E_R = (E_U + 255) / 256, W_R = (W_U + 255) / 256;
+        f32x4 er[E_R], wr[W_R], dr[1];
+        const float* eptr[E_R];
+        bool ein[E_R];
+#pragma unroll
+        for (int i = 0; i < E_R; ++i) {
+            const int u = min(tid + i * 256, E_U - 1);
+            const int hp = u / kCQ, k4 = (u - hp * kCQ) * 4;
+            const int r = hp / IW, cc = hp - r * IW;
+            const int iy = iy0 + r, ix = ix0 + cc;
+            ein[i] = (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+            eptr[i] = eb + ((long)min(max(iy, 0), p.H - 1) * p.W + min(max(ix, 0), p.W - 1)) * p.Ce + k4;
+        }
+        const float* wptr[W_R];
+#pragma unroll
+        for (int i = 0; i < W_R; ++i) {
+            const int u = min(tid + i * 256, W_U - 1);
+            const int row = u / kCQ, k4 = (u - row * kCQ) * 4;
+            wptr[i] = p.wp + (long)min(nt0 * 16 + row, p.npad_p - 1) * p.kpad_p + k4;
+        }
+        const int dt = min(tid, 10 * kCQ - 1) / kCQ, dk4 = (min(tid, 10 * kCQ - 1) % kCQ) * 4;
+        const float* dptr = (dt < 9 ? p.wd + (long)dt * p.Ce : p.dh) + dk4;
+        // (every issued asm load is consumed by the matching store_* below: same chunk conditions)
+        auto load_e = [&](int k) {
+#pragma unroll
+            for (int i = 0; i < E_R; ++i) er[i] = gload16_async(eptr[i] + k * kCK);
+            dr[0] = gload16_async(dptr + k * kCK);
+        };
+        auto load_w = [&](int k) {
+#pragma unroll
+            for (int i = 0; i < W_R; ++i) wr[i] = gload16_async(wptr[i] + k * kCK);
+        };
+        auto store_e = [&](int buf) {
+            wait_prefetch(er);
+            wait_prefetch(dr);
+#pragma unroll
+            for (int i = 0; i < E_R; ++i) {
+                const int u = tid + i * 256;
+                const int hp = u / kCQ, k4 = (u - hp * kCQ) * 4;
+                if (u < E_U)
+                    *reinterpret_cast<f32x4*>(Es + buf * ES + hp * kLD + k4) = ein[i] ? er[i] : f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+            if (tid < 10 * kCQ) *reinterpret_cast<f32x4*>(Wd + buf * WD + dt * kCK + dk4) = dr[0];
+        };
+        auto store_w = [&](int buf) {
+            wait_prefetch(wr);
+#pragma unroll
+            for (int i = 0; i < W_R; ++i) {
+                const int u = tid + i * 256;
+                const int row = u / kCQ, k4 = (u - row * kCQ) * 4;
+                if (u < W_U) *reinterpret_cast<f32x4*>(Ws + buf * WS + row * kLD + k4) = wr[i];
+            }
+        };
+        auto depthwise = [&](int buf) {          // Es/Wd[buf] -> Ds[buf]
+            if (!dw_on || (p.ablate & 1)) return;
+            const float* E = Es + buf * ES;
+            const float* Wt = Wd + buf * WD;
+            float* D = Ds + buf * DS;
+            f32x4 o[SL];
+            const f32x4 sh = *reinterpret_cast<const f32x4*>(Wt + 9 * kCK + cq * 4);
+#pragma unroll
+            for (int j = 0; j < SL; ++j) o[j] = sh;
+#pragma unroll
+            for (int dy = 0; dy < 3; ++dy) {
+                f32x4 win[Sh::WIN];
+                const float* erow = E + ((sr * S + dy) * IW) * kLD + cq * 4;
+#pragma unroll
+                for (int i = 0; i < Sh::WIN; ++i)
+                    win[i] = *reinterpret_cast<const f32x4*>(erow + min(sx0 * S + i, IW - 1) * kLD);
+#pragma unroll
+                for (int dx = 0; dx < 3; ++dx) {
+                    const f32x4 w = *reinterpret_cast<const f32x4*>(Wt + (dy * 3 + dx) * kCK + cq * 4);
+#pragma unroll
+                    for (int j = 0; j < SL; ++j) o[j] += win[j * S + dx] * w;
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < SL; ++j) {
+                if (sx0 + j < TW) {
+                    f32x4 v = o[j];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) v[q] = relu6f(v[q]);
+                    *reinterpret_cast<f32x4*>(D + (sr * TW + sx0 + j) * kLD + cq * 4) = v;
+                }
+            }
+        };
+        // prologue 1: chunk 0 -> Es/Wd[0], Ws[0]
+        load_e(0);
+        load_w(0);
+        store_e(0);
+        store_w(0);
+        if (nchunks > 1) load_e(1);
+        lds_barrier();
+        // prologue 2: D(0); E/wd(1) -> Es/Wd[1]; loads of E/wd(2), Wp(1) in flight
+        depthwise(0);
+        if (nchunks > 1) store_e(1);
+        if (!(p.ablate & 4)) {
+            if (nchunks > 2) load_e(2);
+            if (nchunks > 1) load_w(1);
+        }
+        lds_barrier();
+        for (int i = 0; i < nchunks; ++i) {
+            if (i + 1 < nchunks) depthwise((i + 1) & 1);
+            if (!(p.ablate & 4)) {
+                if (i + 2 < nchunks) store_e(i & 1);
+                if (i + 1 < nchunks) store_w((i + 1) & 1);
+                if (i + 3 < nchunks) load_e(i + 3);
+                if (i + 2 < nchunks) load_w(i + 2);
+            }
+            lds_barrier();
+        }
+        return;
+    }
+
+    // ---- consumers: project MFMAs + epilogue
+    f32x4 acc[MTW][NTW];
+#pragma unroll
+    for (int mi = 0; mi < MTW; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NTW; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int frow = lane & 15, fk = (lane >> 4) * 4;
+    f32x4 shv[NTW];
+#pragma unroll
+    for (int ni = 0; ni < NTW; ++ni) {
+        const int n = (nt0 + wn * NTW + ni) * 16 + (lane >> 4) * 4;
+        shv[ni] = n < p.Cout ? *reinterpret_cast<const f32x4*>(p.ph + n) : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    lds_barrier();
+    lds_barrier();
+    for (int i = 0; i < nchunks; ++i) {
+        const float* D = Ds + (i & 1) * DS;
+        const float* W = Ws + (i & 1) * WS;
+#pragma unroll
+        for (int kc = 0; kc < ((p.ablate & 2) ? 0 : kCK / 16); ++kc) {
+            f32x4 a[NTW], bb[MTW];
+#pragma unroll
+            for (int ni = 0; ni < NTW; ++ni)
+                a[ni] = *reinterpret_cast<const f32x4*>(W + ((wn * NTW + ni) * 16 + frow) * kLD + kc * 16 + fk);
+#pragma unroll
+            for (int mi = 0; mi < MTW; ++mi)
+                bb[mi] = *reinterpret_cast<const f32x4*>(D + ((wm * MTW + mi) * 16 + frow) * kLD + kc * 16 + fk);
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+#pragma unroll
+                for (int mi = 0; mi < MTW; ++mi)
+#pragma unroll
+                    for (int ni = 0; ni < NTW; ++ni)
+                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[ni][s], bb[mi][s], acc[mi][ni], 0, 0, 0);
+        }
+        lds_barrier();
+    }
+#pragma unroll
+    for (int mi = 0; mi < MTW; ++mi) {
+        const int px = (wm * MTW + mi) * 16 + (lane & 15);
+        const int r = px / TW, cc = px - r * TW;
+        const int oy = oy0 + r, ox = ox0 + cc;
+        if (px >= PT || oy >= p.Ho || ox >= p.Wo) continue;
+        const long o = (((long)b * p.Ho + oy) * p.Wo + ox) * p.Cout;
+#pragma unroll
+        for (int ni = 0; ni < NTW; ++ni) {
+            const int n = (nt0 + wn * NTW + ni) * 16 + (lane >> 4) * 4;
+            if (n >= p.Cout) continue;
+            f32x4 v = acc[mi][ni] + shv[ni];
+            if (p.res) v = v + *reinterpret_cast<const f32x4*>(p.res + o + n);
+            *reinterpret_cast<f32x4*>(p.y + o + n) = v;
+        }
+    }
+}
+
 typedef void (*dwproj_fn)(const DwProjParams);
 struct DwProjCfg {
     int stride, cout_min, cout_max, th, tw, ntb, n_split;
     size_t lds;
     dwproj_fn fn;
+    size_t lds8;
+    dwproj_fn fn8;
 };
 #define DCFG(S, TH, TW, SL, WM, WN, NTW, CMIN, CMAX, NSPLIT)                                               \
     {S, CMIN, CMAX, TH, TW, NTW * WN, NSPLIT, DwProjShape<S, TH, TW, SL, WM, WN, NTW>::lds_floats * 4,       \
-     dwproj_kernel<S, TH, TW, SL, WM, WN, NTW>}
+     dwproj_kernel<S, TH, TW, SL, WM, WN, NTW>, DwProjShape<S, TH, TW, SL, WM, WN, NTW>::lds_floats * 8,      \
+     dwproj8_kernel<S, TH, TW, SL, WM, WN, NTW>}
 const DwProjCfg kDwProj[] = {
     // stride 1, 19-wide row bands (blocks 7-12 of SSD300): 6 pixel groups x Cout/16 tiles on 2x2 waves
     DCFG(1, 5, 19, 5, 2, 2, 2, 1, 64, 1),
@@ -285,6 +497,15 @@ int launch_dwproj(DwProjParams p, hipStream_t st) {
     p.tiles_x = (p.Wo + c->tw - 1) / c->tw;
     const long tiles = (long)p.B * p.tiles_y * p.tiles_x;
     SSD_UNSUPPORTED_IF(tiles > 0x7fffffffL, "dw+project: grid too large");
+    static const int ablate = getenv("SSD_DWPROJ_ABLATE") ? atoi(getenv("SSD_DWPROJ_ABLATE")) : 0;
+    p.ablate = ablate;
+    static const int waves = getenv("SSD_DWPROJ_WAVES") ? atoi(getenv("SSD_DWPROJ_WAVES")) : 8;     // diagnostics knob
+    if (waves == 8 && c->lds8 <= 160 * 1024) {
+        SSD_HIP(hipFuncSetAttribute((const void*)c->fn8, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds8));
+        hipLaunchKernelGGL(c->fn8, dim3((unsigned)tiles, c->n_split), dim3(512), c->lds8, st, p);
+        SSD_LAUNCH_CHECK();
+        return SSD_OK;
+    }
     if (c->lds > 64 * 1024)
         SSD_HIP(hipFuncSetAttribute((const void*)c->fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds));
     hipLaunchKernelGGL(c->fn, dim3((unsigned)tiles, c->n_split), dim3(256), c->lds, st, p);
