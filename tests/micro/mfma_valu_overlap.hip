@@ -23,11 +23,17 @@ __global__ __launch_bounds__(512) void k(float* out, int iters_mfma, int iters_b
             float a = threadIdx.x * 0.001f, b = threadIdx.x * 0.002f;
             for (int it = 0; it < iters_mfma; ++it) {
 #pragma unroll
-                for (int i = 0; i < 8; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[i], 0, 0, 0);
+                for (int i = 0; i < 8; ++i) {
+                    acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[i], 0, 0, 0);
+                    // mode & 8: idle the MFMA wave while its MFMA executes, so that its NEXT MFMA does
+                    // not sit in the issue stage (does a waiting MFMA block the SIMD's other waves?)
+                    if (mode & 8) asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 7" ::: "memory");
+                }
             }
             for (int i = 0; i < 8; ++i) s += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
         }
     } else if (mode & 2) {
+        if (mode & 4) __builtin_amdgcn_s_setprio(3);     // role waves above the MFMA waves
         if (ROLE == 0) {
             float v[16];
             for (int i = 0; i < 16; ++i) v[i] = threadIdx.x + i;
@@ -53,7 +59,7 @@ __global__ __launch_bounds__(512) void k(float* out, int iters_mfma, int iters_b
 #pragma unroll
                 for (int i = 0; i < 8; ++i) {
                     f32x4 r = *reinterpret_cast<const volatile f32x4*>(base + i * 1024);
-                    t += r;
+                    asm volatile("" ::"v"(r));          // consumed without VALU work
                 }
             }
             s = t[0] + t[1] + t[2] + t[3];
@@ -86,8 +92,12 @@ int main() {
         if (r == 0) { a = run(k<0>, im, roles[r].iters, 1); b = run(k<0>, im, roles[r].iters, 2); c = run(k<0>, im, roles[r].iters, 3); }
         else if (r == 1) { a = run(k<1>, im, roles[r].iters, 1); b = run(k<1>, im, roles[r].iters, 2); c = run(k<1>, im, roles[r].iters, 3); }
         else { a = run(k<2>, im, roles[r].iters, 1); b = run(k<2>, im, roles[r].iters, 2); c = run(k<2>, im, roles[r].iters, 3); }
-        printf("%-28s MFMA alone %.3f ms | role alone %.3f ms | together %.3f ms  (max %.3f, sum %.3f)\n", roles[r].name, a, b, c,
-               a > b ? a : b, a + b);
+        float d = r == 0 ? run(k<0>, im, roles[r].iters, 7) : r == 1 ? run(k<1>, im, roles[r].iters, 7) : run(k<2>, im, roles[r].iters, 7);
+        float e = r == 0 ? run(k<0>, im, roles[r].iters, 9) : r == 1 ? run(k<1>, im, roles[r].iters, 9) : run(k<2>, im, roles[r].iters, 9);
+        float f = r == 0 ? run(k<0>, im, roles[r].iters, 11) : r == 1 ? run(k<1>, im, roles[r].iters, 11) : run(k<2>, im, roles[r].iters, 11);
+        printf("%-28s MFMA alone %.3f ms | role alone %.3f ms | together %.3f ms | together, role waves s_setprio(3) %.3f ms  (max %.3f, sum %.3f)\n"
+               "%-28s MFMA + 24 idle cycles after each: alone %.3f ms | together %.3f ms\n",
+               roles[r].name, a, b, c, d, a > b ? a : b, a + b, "", e, f);
     }
     return 0;
 }

@@ -587,6 +587,14 @@ static const ConvCfg kCfgs[] = {
     CFG(2, 4, 2, 2, 64),
     CFG(1, 1, 4, 1, 64),
     CFG(2, 2, 2, 2, 64),
+    // 30..: large per-wave tiles (more MFMAs per fragment read / staged byte; 1 workgroup per CU)
+    CFG(4, 5, 2, 2, 32),   // 128 x 160
+    CFG(4, 7, 4, 1, 32),   // 256 x 112
+    CFG(4, 4, 4, 1, 32),   // 256 x 64
+    CFG(4, 6, 4, 1, 32),   // 256 x 96
+    CFG(4, 3, 4, 1, 32),   // 256 x 48
+    CFG(4, 5, 4, 1, 32),   // 256 x 80
+    CFG(2, 10, 2, 2, 32),  // 64 x 320
 };
 constexpr int kNumMfmaCfgs = sizeof(kCfgs) / sizeof(kCfgs[0]);
 constexpr int kDirectCfg = kNumMfmaCfgs;       // last config id = VALU direct kernel

@@ -253,7 +253,7 @@ __global__ __launch_bounds__(256) void dwproj_kernel(const DwProjParams p) {
 //   consumers, iteration i:  acc += Ds[i&1] x Ws[i&1]
 // (a phase ablation of the 4-wave kernel showed its depthwise, MFMA and staging times simply add
 // up: 6.4 + 8.5 + 4.3 us of a 33 us block_7 launch, 10.9 + 20.4 + 9.7 of 55 us for block_11.)
-template <int S, int TH, int TW, int SL, int WM, int WN, int NTW>
+template <int S, int TH, int TW, int SL, int WM, int WN, int NTW, int NOPS>
 __global__ __launch_bounds__(512) void dwproj8_kernel(const DwProjParams p) {
     using Sh = DwProjShape<S, TH, TW, SL, WM, WN, NTW>;
     constexpr int PT = Sh::PT, PG = Sh::PG, MTW = Sh::MTW, NTB = Sh::NTB, IW = Sh::IW, HP = Sh::HP;
@@ -428,8 +428,13 @@ __global__ __launch_bounds__(512) void dwproj8_kernel(const DwProjParams p) {
 #pragma unroll
                 for (int mi = 0; mi < MTW; ++mi)
 #pragma unroll
-                    for (int ni = 0; ni < NTW; ++ni)
+                    for (int ni = 0; ni < NTW; ++ni) {
                         acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[ni][s], bb[mi][s], acc[mi][ni], 0, 0, 0);
+                        // A wave whose NEXT MFMA waits in the issue stage for the matrix pipe blocks every
+                        // other wave of its SIMD (tests/micro/mfma_valu_overlap.hip): idle through the
+                        // 8-pass shadow instead, so that the producer wave sharing the SIMD can issue.
+                        if (NOPS > 0) asm volatile("s_nop %0" ::"n"(NOPS));
+                    }
         }
         lds_barrier();
     }
@@ -457,12 +462,13 @@ struct DwProjCfg {
     size_t lds;
     dwproj_fn fn;
     size_t lds8;
-    dwproj_fn fn8;
+    dwproj_fn fn8[4];       // s_nop 0 (none) / 3 / 5 / 6 after each consumer MFMA
 };
 #define DCFG(S, TH, TW, SL, WM, WN, NTW, CMIN, CMAX, NSPLIT)                                               \
     {S, CMIN, CMAX, TH, TW, NTW * WN, NSPLIT, DwProjShape<S, TH, TW, SL, WM, WN, NTW>::lds_floats * 4,       \
      dwproj_kernel<S, TH, TW, SL, WM, WN, NTW>, DwProjShape<S, TH, TW, SL, WM, WN, NTW>::lds_floats * 8,      \
-     dwproj8_kernel<S, TH, TW, SL, WM, WN, NTW>}
+     {dwproj8_kernel<S, TH, TW, SL, WM, WN, NTW, 0>, dwproj8_kernel<S, TH, TW, SL, WM, WN, NTW, 3>,              \
+      dwproj8_kernel<S, TH, TW, SL, WM, WN, NTW, 5>, dwproj8_kernel<S, TH, TW, SL, WM, WN, NTW, 6>}}
 const DwProjCfg kDwProj[] = {
     // stride 1, 19-wide row bands (blocks 7-12 of SSD300): 6 pixel groups x Cout/16 tiles on 2x2 waves
     DCFG(1, 5, 19, 5, 2, 2, 2, 1, 64, 1),
@@ -500,9 +506,11 @@ int launch_dwproj(DwProjParams p, hipStream_t st) {
     static const int ablate = getenv("SSD_DWPROJ_ABLATE") ? atoi(getenv("SSD_DWPROJ_ABLATE")) : 0;
     p.ablate = ablate;
     static const int waves = getenv("SSD_DWPROJ_WAVES") ? atoi(getenv("SSD_DWPROJ_WAVES")) : 8;     // diagnostics knob
+    static const int nopsel = getenv("SSD_DWPROJ_NOP") ? atoi(getenv("SSD_DWPROJ_NOP")) & 3 : 0;     // diagnostics knob
     if (waves == 8 && c->lds8 <= 160 * 1024) {
-        SSD_HIP(hipFuncSetAttribute((const void*)c->fn8, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds8));
-        hipLaunchKernelGGL(c->fn8, dim3((unsigned)tiles, c->n_split), dim3(512), c->lds8, st, p);
+        dwproj_fn fn8 = c->fn8[nopsel];
+        SSD_HIP(hipFuncSetAttribute((const void*)fn8, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds8));
+        hipLaunchKernelGGL(fn8, dim3((unsigned)tiles, c->n_split), dim3(512), c->lds8, st, p);
         SSD_LAUNCH_CHECK();
         return SSD_OK;
     }
