@@ -417,10 +417,7 @@ __global__ __launch_bounds__(256) void conv_direct_kernel(const ConvParams p) {
                 for (int ci = 0; ci < p.Cin; ++ci) {
                     const float x = xp[ci];
                     const f32x4 w4 = *reinterpret_cast<const f32x4*>(wp + ci * Cout4);
-                    acc[0] = fmaf(x, w4[0], acc[0]);
-                    acc[1] = fmaf(x, w4[1], acc[1]);
-                    acc[2] = fmaf(x, w4[2], acc[2]);
-                    acc[3] = fmaf(x, w4[3], acc[3]);
+                    acc += x * w4;
                 }
             }
         }
@@ -493,10 +490,7 @@ __global__ __launch_bounds__(256) void conv_stem_kernel(const ConvParams p) {
                         const f32x4 w4 = *reinterpret_cast<const f32x4*>(wk + c * 4);
 #pragma unroll
                         for (int q = 0; q < PX; ++q) {
-                            acc[q][c][0] = fmaf(x[q][ci], w4[0], acc[q][c][0]);
-                            acc[q][c][1] = fmaf(x[q][ci], w4[1], acc[q][c][1]);
-                            acc[q][c][2] = fmaf(x[q][ci], w4[2], acc[q][c][2]);
-                            acc[q][c][3] = fmaf(x[q][ci], w4[3], acc[q][c][3]);
+                            acc[q][c] += x[q][ci] * w4;      // v_pk_fma_f32
                         }
                     }
                 }

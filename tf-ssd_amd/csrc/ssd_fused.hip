@@ -282,7 +282,7 @@ __global__ __launch_bounds__(256, 2) void mbv2_block_kernel(const FusedBlockPara
                     expand_px_tiles<1, CINP, IW, IPX>(Xs, Wes, Es, Ps, Ce, ce0, pt, pt, lane, iy0, ix0, p.H, p.W, p.ablate);
             }
             if (getenv_dbg_split) TICK(4);      // diagnostics: slot 4 = expand compute (+ weight staging), slot 1 = its barrier wait
-            lds_barrier();
+            if (!(p.ablate & 16)) lds_barrier();
             TICK(1);
 
             // ---- phase B: depthwise 3x3 + BN + ReLU6 (VALU, LDS -> LDS), sliding register window
@@ -304,11 +304,7 @@ __global__ __launch_bounds__(256, 2) void mbv2_block_kernel(const FusedBlockPara
                         const f32x4 w = *reinterpret_cast<const f32x4*>(Ps + (2 + ky * 3 + kx) * Ce + ce0 + bc4);
 #pragma unroll
                         for (int t = 0; t < SL; ++t) {
-                            const f32x4 x = e[t * S + kx];
-                            a[t][0] = fmaf(x[0], w[0], a[t][0]);
-                            a[t][1] = fmaf(x[1], w[1], a[t][1]);
-                            a[t][2] = fmaf(x[2], w[2], a[t][2]);
-                            a[t][3] = fmaf(x[3], w[3], a[t][3]);
+                            a[t] += e[t * S + kx] * w;        // vector form: contracts to v_pk_fma_f32
                         }
                     }
                 }
@@ -320,7 +316,7 @@ __global__ __launch_bounds__(256, 2) void mbv2_block_kernel(const FusedBlockPara
                     *reinterpret_cast<f32x4*>(Ds + (boy * TW + box0 + t) * kLDE + bc4) = v;
                 }
             }
-            lds_barrier();
+            if (!(p.ablate & 16)) lds_barrier();
             TICK(2);
 
             // ---- phase C: project (MFMA), accumulators stay in registers across chunks
@@ -338,11 +334,11 @@ __global__ __launch_bounds__(256, 2) void mbv2_block_kernel(const FusedBlockPara
                     for (int ni = 0; ni < NTW; ++ni)
                         acc[ni] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[ni][s], db[s], acc[ni], 0, 0, 0);
             }
-            lds_barrier();
+            if (!(p.ablate & 16)) lds_barrier();
             TICK(3);
             if (ch + 1 < nchunk) {
                 store_w();
-                lds_barrier();
+                if (!(p.ablate & 16)) lds_barrier();
             }
             TICK(4);
         }
@@ -367,10 +363,10 @@ __global__ __launch_bounds__(256, 2) void mbv2_block_kernel(const FusedBlockPara
             }
         }
         if (next < total_tiles) {
-            lds_barrier();          // every wave is done with Xs (residual) before it is replaced
+            if (!(p.ablate & 16)) lds_barrier();          // every wave is done with Xs (residual) before it is replaced
             store_x(next);
             store_w();
-            lds_barrier();
+            if (!(p.ablate & 16)) lds_barrier();
         }
         TICK(5);
     }
@@ -537,10 +533,8 @@ __global__ __launch_bounds__(256) void mbv2_stem_kernel(const StemParams p) {
                     const float x = pp[ky * kSPW * 3 + kk];
                     const float* wk = W1 + (ky * 9 + kk) * 32 + cg;
                     const f32x4 w0 = *reinterpret_cast<const f32x4*>(wk), w1 = *reinterpret_cast<const f32x4*>(wk + 4);
-                    a0[0] = fmaf(x, w0[0], a0[0]); a0[1] = fmaf(x, w0[1], a0[1]);
-                    a0[2] = fmaf(x, w0[2], a0[2]); a0[3] = fmaf(x, w0[3], a0[3]);
-                    a1[0] = fmaf(x, w1[0], a1[0]); a1[1] = fmaf(x, w1[1], a1[1]);
-                    a1[2] = fmaf(x, w1[2], a1[2]); a1[3] = fmaf(x, w1[3], a1[3]);
+                    a0 += x * w0;                                  // scalar x broadcast: v_pk_fma_f32
+                    a1 += x * w1;
                 }
             const bool in = (unsigned)(cy0 + r) < (unsigned)p.H1 && (unsigned)(cx0 + c) < (unsigned)p.W1;
 #pragma unroll
@@ -568,8 +562,7 @@ __global__ __launch_bounds__(256) void mbv2_stem_kernel(const StemParams p) {
                     const f32x4 w = *reinterpret_cast<const f32x4*>(Wd + (ky * 3 + kx) * 32 + c4);
 #pragma unroll
                     for (int t = 0; t < 4; ++t) {
-                        a[t][0] = fmaf(e[t + kx][0], w[0], a[t][0]); a[t][1] = fmaf(e[t + kx][1], w[1], a[t][1]);
-                        a[t][2] = fmaf(e[t + kx][2], w[2], a[t][2]); a[t][3] = fmaf(e[t + kx][3], w[3], a[t][3]);
+                        a[t] += e[t + kx] * w;
                     }
                 }
             }

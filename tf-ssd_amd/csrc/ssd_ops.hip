@@ -62,10 +62,7 @@ __global__ __launch_bounds__(256) void dwconv3x3_kernel(
                 for (int kx = 0; kx < 3; ++kx) {
                     const f32x4 x = xin[t * STRIDE + kx];
                     const f32x4 ww = wv[ky * 3 + kx];
-                    acc[t][0] = fmaf(x[0], ww[0], acc[t][0]);
-                    acc[t][1] = fmaf(x[1], ww[1], acc[t][1]);
-                    acc[t][2] = fmaf(x[2], ww[2], acc[t][2]);
-                    acc[t][3] = fmaf(x[3], ww[3], acc[t][3]);
+                    acc[t] += x * ww;          // vector form: contracts to v_pk_fma_f32
                 }
         }
         f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
