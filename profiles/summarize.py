@@ -30,7 +30,7 @@ if stats:
     fam = defaultdict(lambda: [0, 0.0])
     for r in rows:
         n = short(r["Name"])
-        key = n.split("<")[0].split("(")[0]
+        key = n.replace("(anonymous namespace)::", "").split("<")[0].split("(")[0]
         fam[key][0] += int(r["Calls"])
         fam[key][1] += float(r["TotalDurationNs"]) / 1e3
     tot = sum(v[1] for v in fam.values())
@@ -53,7 +53,7 @@ for tag, counter in (("pmc_fetch", "FETCH_SIZE"), ("pmc_write", "WRITE_SIZE")):
         agg[k][1] += float(r["Counter_Value"])
     famagg = defaultdict(lambda: [0, 0.0])
     for k, (n, v) in agg.items():
-        key = k.split("<")[0].split("(")[0]
+        key = k.replace("(anonymous namespace)::", "").split("<")[0].split("(")[0]
         famagg[key][0] += n
         famagg[key][1] += v
     print("\n== rocprofv3 --pmc %s by kernel family" % counter)

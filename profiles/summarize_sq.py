@@ -13,7 +13,7 @@ if not files:
 agg = defaultdict(lambda: defaultdict(float))
 calls = defaultdict(set)
 for r in csv.DictReader(open(files[0])):
-    k = r["Kernel_Name"].replace("ssd::", "").replace("void ", "")
+    k = r["Kernel_Name"].replace("ssd::", "").replace("void ", "").replace("(anonymous namespace)::", "")
     k = k.split("(")[0][:70]
     agg[k][r["Counter_Name"]] += float(r["Counter_Value"])
     calls[k].add(r["Dispatch_Id"])
