@@ -112,31 +112,36 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvParams p) {
 
     // uniform state of the tile being loaded: k0, its tap (general path) and byte offsets
     int l_k0 = 0, l_tap = 0, l_ci = 0, l_ky = 0, l_kx = 0, l_xtile = 0;
+    // General path: the K tiles are walked channel-slice-major, taps innermost -- tile t covers
+    // tap t % (kh*kw) of input channels [(t / (kh*kw)) * BK, +BK).  The kh*kw taps of one channel
+    // slice re-read the same 128-byte pixel lines, so they hit in L1/L2 back to back; with the
+    // tap-major order (whole Cin per tap) every tap re-fetched the block's input region from
+    // the fabric (FETCH_SIZE of the 3x3 head conv: 6.7x its algorithmic bytes).
+    const int ntaps = p.kh * p.kw;
     auto tile_setup = [&](int kt) {            // once; afterwards tile_advance()
-        l_k0 = kt * BK;
         if (GEMM1X1) {
+            l_k0 = kt * BK;
             l_xtile = l_k0 * 4;
         } else {
-            l_tap = l_k0 / p.Cin;
-            l_ci = l_k0 - l_tap * p.Cin;
+            const int cs = kt / ntaps;
+            l_tap = kt - cs * ntaps;
+            l_ci = cs * BK;
             l_ky = l_tap / p.kw;
             l_kx = l_tap - l_ky * p.kw;
+            l_k0 = l_tap * p.Cin + l_ci;
             l_xtile = ((l_ky * p.dil * p.W + l_kx * p.dil) * p.Cin + l_ci) * 4;
         }
     };
     auto tile_advance = [&]() {                // kt -> kt + 1 (Cin % BK == 0 on the general path)
-        l_k0 += BK;
         if (GEMM1X1) {
+            l_k0 += BK;
             l_xtile += BK * 4;
         } else {
-            l_ci += BK;
-            l_xtile += BK * 4;
-            if (l_ci >= p.Cin) {
-                l_ci = 0;
-                ++l_tap;
-                if (++l_kx == p.kw) { l_kx = 0; ++l_ky; }
-                l_xtile = (l_ky * p.dil * p.W + l_kx * p.dil) * p.Cin * 4;
-            }
+            ++l_tap;
+            if (++l_kx == p.kw) { l_kx = 0; ++l_ky; }
+            if (l_tap == ntaps) { l_tap = 0; l_ky = 0; l_kx = 0; l_ci += BK; }
+            l_k0 = l_tap * p.Cin + l_ci;
+            l_xtile = ((l_ky * p.dil * p.W + l_kx * p.dil) * p.Cin + l_ci) * 4;
         }
     };
     auto x_is_valid = [&](int ps) -> bool {
