@@ -132,6 +132,23 @@ def main():
                 r["name"], r["kind"], r["config"], r["ms"], r["flops"] / 1e9, r["bytes"] / 1e6,
                 r["flops"] / max(r["ms"], 1e-9) / 1e9, r["bytes"] / max(r["ms"], 1e-9) / 1e6))
 
+    # HBM-side traffic of the family, per launch: PMC counters cannot be read from inside this
+    # process, so the value comes from the committed rocprofv3 --pmc passes of this same command
+    # (profiles/traffic_<backbone>_b<B>.json, written by profiles/collect.sh); null if absent.
+    traffic, traffic_detail = None, None
+    tpath = os.path.join(REPO, "profiles", "traffic_%s_b%d.json" % (args.backbone, B))
+    if os.path.exists(tpath) and hp["img_size"] == 300:
+        try:
+            fam = json.load(open(tpath))["families"]["conv_mfma_kernel"]
+            fetch = 2.0 * fam["FETCH_SIZE"]["KB_per_launch_reported"] * 1024.0      # gfx950: x2 for wide reads
+            write = fam["WRITE_SIZE"]["KB_per_launch_reported"] * 1024.0
+            traffic = fetch + write
+            traffic_detail = {"fetch_bytes_per_launch_x2_corrected": fetch, "write_bytes_per_launch": write,
+                              "algorithmic_bytes_per_launch": sum(r["bytes"] for r in mfma) / max(len(mfma), 1),
+                              "source": "profiles/" + os.path.basename(tpath)}
+        except (KeyError, ValueError):
+            pass
+
     result = {
         "metric": "images/sec SSD%d (%s) fwd+NMS" % (hp["img_size"], "MobileNetV2" if args.backbone == "mobilenet_v2" else "VGG16"),
         "value": world * B * args.steps / elapsed,
@@ -152,7 +169,7 @@ def main():
                    "mean_detections_per_image": mean_det, "parallelism": "batch-sharded x%d, no collective" % world},
         "roofline": {"bound": "mfma", "kernel": "conv_mfma_kernel (fp32 v_mfma_f32_16x16x4 implicit-GEMM conv, all tile configs)",
                      "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                     "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": None,
+                     "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": traffic, "traffic_detail": traffic_detail,
                      "launches_per_step": len(mfma), "kernel_ms_per_step": mfma_ms,
                      "algorithmic_gflop_per_step": mfma_flops / 1e9},
         "gpu_ms_per_step_by_kind": {k: round(v, 4) for k, v in sorted(kinds.items())},

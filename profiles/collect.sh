@@ -16,5 +16,5 @@ timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -
 timeout 900 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch -o f -- $CMD > $OUT/bench_fetch.log 2>&1
 timeout 900 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write -o w -- $CMD > $OUT/bench_write.log 2>&1
 find $OUT -name "*.csv" | head -20
-python profiles/summarize.py $OUT > $OUT/summary.txt 2>&1
+TRAFFIC_JSON=$OUT/traffic.json python profiles/summarize.py $OUT > $OUT/summary.txt 2>&1
 tail -60 $OUT/summary.txt
