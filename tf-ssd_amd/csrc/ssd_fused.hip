@@ -94,6 +94,27 @@ __device__ __forceinline__ void expand_px_tiles(const float* Xs, const float* We
                 for (int ct = 0; ct < 3; ++ct)
                     ea[q][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[ct][s], xb4[q][s], ea[q][ct], 0, 0, 0);
     }
+    if (CINP % 16 == 8 && !(ablate & 1)) {
+        // K tail of 8 (Cin = 24): lane group g reads k = 16*(CINP/16) + 2g + {0, 1} with one
+        // ds_read_b64, i.e. 2 MFMA k-steps instead of the 4 a zero-padded 16-wide unit would cost
+        typedef float f32x2 __attribute__((ext_vector_type(2)));
+        constexpr int K0 = CINP / 16 * 16;
+        const int fk2 = (lane >> 4) * 2;
+        f32x2 xb2[NP], wa2[3];
+#pragma unroll
+        for (int q = 0; q < NP; ++q)
+            xb2[q] = *reinterpret_cast<const f32x2*>(Xs + (pts[q] * 16 + frow) * LDX + K0 + fk2);
+#pragma unroll
+        for (int ct = 0; ct < 3; ++ct)
+            wa2[ct] = *reinterpret_cast<const f32x2*>(Wes + (ct * 16 + frow) * LDX + K0 + fk2);
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int q = 0; q < NP; ++q)
+#pragma unroll
+                for (int ct = 0; ct < 3; ++ct)
+                    ea[q][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa2[ct][s], xb2[q][s], ea[q][ct], 0, 0, 0);
+    }
     // lane holds E[px = pt*16 + (lane & 15)][ce = ct*16 + (lane >> 4)*4 + 0..3]
 #pragma unroll
     for (int q = 0; q < NP; ++q) {
@@ -394,7 +415,9 @@ struct FusedCfg {
      mbv2_block_kernel<CINP, NTC, S, TH, TW, RES != 0>}
 static const FusedCfg kFused[] = {
     FCFG(16, 2, 2, 4, 8, 0),   // block_1: 16 -> 96 -> 24, stride 2
-    FCFG(32, 2, 1, 8, 8, 1),   // block_2 / 4 / 5: residual, Cout <= 32
+    FCFG(24, 2, 1, 8, 8, 1),   // block_2: 24 -> 144 -> 24 (K = 24: 6 MFMA k-steps, not 8)
+    FCFG(24, 2, 2, 4, 8, 0),   // block_3: 24 -> 144 -> 32, stride 2
+    FCFG(32, 2, 1, 8, 8, 1),   // block_4 / 5: residual, Cout <= 32
     FCFG(32, 2, 1, 8, 8, 0),
     FCFG(32, 2, 2, 4, 8, 0),   // block_3: 24 -> 144 -> 32, stride 2
     FCFG(32, 4, 2, 4, 8, 0),   // block_6: 32 -> 192 -> 64, stride 2
@@ -404,7 +427,7 @@ static const FusedCfg kFused[] = {
 
 static const FusedCfg* pick_fused(const FusedBlockParams& p) {
     if (p.Ce % kCK != 0 || p.Cin % 4 != 0 || p.Cout % 4 != 0) return nullptr;
-    const int cinp = p.Cin <= 16 ? 16 : (p.Cin <= 32 ? 32 : 0);
+    const int cinp = p.Cin <= 16 ? 16 : (p.Cin == 24 ? 24 : (p.Cin <= 32 ? 32 : 0));
     const int ntc = p.Cout <= 32 ? 2 : (p.Cout <= 64 ? 4 : 0);
     if (!cinp || !ntc) return nullptr;
     for (const auto& c : kFused)
