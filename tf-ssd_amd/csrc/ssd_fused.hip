@@ -121,13 +121,16 @@ __device__ __forceinline__ void expand_px_tiles(const float* Xs, const float* We
         const int hp = pts[q] * 16 + (lane & 15);
         const int r = hp / IW, c = hp - r * IW;
         const bool inimg = hp < IPX && (unsigned)(iy0 + r) < (unsigned)H && (unsigned)(ix0 + c) < (unsigned)W;
+        const float hi = inimg ? 6.0f : 0.0f;
 #pragma unroll
         for (int ct = 0; ct < 3; ++ct) {
             const int cl = ct * 16 + (lane >> 4) * 4;
             f32x4 v = ea[q][ct];
+            // relu6 inside the image, 0 outside it (the depthwise pads E): one v_med3 with a
+            // per-lane upper bound of 6 or 0 instead of med3 + select
             if (!(ablate & 8))
 #pragma unroll
-            for (int j = 0; j < 4; ++j) v[j] = inimg ? relu6f(v[j]) : 0.0f;
+            for (int j = 0; j < 4; ++j) v[j] = __builtin_amdgcn_fmed3f(v[j], 0.0f, hi);
             *reinterpret_cast<f32x4*>(Es + hp * kLDE + cl) = v;
         }
     }
