@@ -60,6 +60,7 @@ struct StemParams {
     const float *sp, *hp;       // folded project BN [16]
     int B, H, W, H1, W1, pad_t, pad_l, kpad1, kpadp;
     int tiles_y, tiles_x;
+    int ablate;                 // diagnostics (SSD_STEM_ABLATE): 1 skip Conv1 math, 2 depthwise, 4 project MFMAs, 8 patch loads
 };
 // Depthwise 3x3 + BN + ReLU6 -> project 1x1 + BN (+ residual) of one MobileNetV2 block
 // (csrc/ssd_dwproj.hip); BN scales are folded into wd / wp by the caller.

@@ -501,9 +501,17 @@ __global__ __launch_bounds__(256) void mbv2_stem_kernel(const StemParams p) {
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     // weights (BatchNorm scale folded in) are staged once per persistent workgroup
-    for (int e = tid; e < 27 * 32; e += 256) {                 // packed [n][kpad] -> [k][n]
-        const int k = e >> 5, n = e & 31;
-        W1[e] = p.w1[(long)n * p.kpad1 + k] * p.s1[n];
+    // Conv1: the 27 x 4 weights (x BN scale) of this thread's 4 output channels stay in registers
+    // for the whole persistent loop -- the phase was LDS-read bound with the weights in LDS (3
+    // LDS reads per 4 packed FMAs; 100 of the kernel's 176 us)
+    const int c1g = (tid & 7) * 4;
+    f32x4 w1r[27], h1r;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const float sc = p.s1[c1g + j];
+        h1r[j] = p.h1[c1g + j];
+#pragma unroll
+        for (int k = 0; k < 27; ++k) w1r[k][j] = p.w1[(long)(c1g + j) * p.kpad1 + k] * sc;
     }
     for (int e = tid; e < 9 * 32; e += 256) Wd[e] = p.wd[e] * p.sd[e & 31];
     for (int e = tid; e < 16 * 32; e += 256) {
@@ -535,7 +543,7 @@ __global__ __launch_bounds__(256) void mbv2_stem_kernel(const StemParams p) {
                 const int r = e / (kSPW * 3), j = e - r * (kSPW * 3);
                 const int iy = iy0 + r, ixc = ix0 * 3 + j;         // ixc = ix * 3 + channel
                 tmp[i] = 0.f;
-                if (e < kSPH * kSPW * 3 && (unsigned)iy < (unsigned)p.H && ixc >= 0 && ixc < p.W * 3)
+                if (!(p.ablate & 8) && e < kSPH * kSPW * 3 && (unsigned)iy < (unsigned)p.H && ixc >= 0 && ixc < p.W * 3)
                     tmp[i] = img[(long)iy * p.W * 3 + ixc];
             }
 #pragma unroll
@@ -546,32 +554,28 @@ __global__ __launch_bounds__(256) void mbv2_stem_kernel(const StemParams p) {
         }
         __syncthreads();
 
-        // ---- Conv1 on the halo: item = (halo pixel, 8-channel group)
-        for (int it = tid; it < kSIH * kSIW * 4; it += 256) {
-            const int cg = (it & 3) * 8, hp = it >> 2;
+        // ---- Conv1 on the halo: item = (halo pixel, 4-channel group); it & 7 == tid & 7
+        for (int it = tid; it < ((p.ablate & 1) ? 0 : kSIH * kSIW * 8); it += 256) {
+            const int hp = it >> 3;
             const int r = hp / kSIW, c = hp - r * kSIW;
-            f32x4 a0 = *reinterpret_cast<const f32x4*>(H1 + cg), a1 = *reinterpret_cast<const f32x4*>(H1 + cg + 4);
+            f32x4 a = h1r;
             const float* pp = patch + ((2 * r) * kSPW + 2 * c) * 3;
 #pragma unroll
             for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
-                for (int kk = 0; kk < 9; ++kk) {                    // (kx, ci) are contiguous in the patch row
-                    const float x = pp[ky * kSPW * 3 + kk];
-                    const float* wk = W1 + (ky * 9 + kk) * 32 + cg;
-                    const f32x4 w0 = *reinterpret_cast<const f32x4*>(wk), w1 = *reinterpret_cast<const f32x4*>(wk + 4);
-                    a0 += x * w0;                                  // scalar x broadcast: v_pk_fma_f32
-                    a1 += x * w1;
-                }
+                for (int kk = 0; kk < 9; ++kk)                      // (kx, ci) are contiguous in the patch row
+                    a += pp[ky * kSPW * 3 + kk] * w1r[ky * 9 + kk];
+            // ReLU6 inside the feature map, 0 outside (the depthwise pads Conv1's OUTPUT)
             const bool in = (unsigned)(cy0 + r) < (unsigned)p.H1 && (unsigned)(cx0 + c) < (unsigned)p.W1;
+            const float hi = in ? 6.0f : 0.0f;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) { a0[j] = in ? relu6f(a0[j]) : 0.f; a1[j] = in ? relu6f(a1[j]) : 0.f; }
-            *reinterpret_cast<f32x4*>(C1 + hp * kSLD + cg) = a0;
-            *reinterpret_cast<f32x4*>(C1 + hp * kSLD + cg + 4) = a1;
+            for (int j = 0; j < 4; ++j) a[j] = __builtin_amdgcn_fmed3f(a[j], 0.0f, hi);
+            *reinterpret_cast<f32x4*>(C1 + hp * kSLD + c1g) = a;
         }
         __syncthreads();
 
         // ---- depthwise: thread = 4 channels x 4 consecutive columns (8 rows x 4 strips x 8 groups = 256)
-        {
+        if (!(p.ablate & 2)) {
             const int c4 = (tid & 7) * 4, strip = tid >> 3;
             const int oy = strip >> 2, ox = (strip & 3) * 4;
             f32x4 a[4];
@@ -607,7 +611,7 @@ __global__ __launch_bounds__(256) void mbv2_stem_kernel(const StemParams p) {
         f32x4 acc[2];
         acc[0] = acc[1] = *reinterpret_cast<const f32x4*>(Hp + (lane >> 4) * 4);
 #pragma unroll
-        for (int kc = 0; kc < 2; ++kc) {
+        for (int kc = 0; kc < ((p.ablate & 4) ? 0 : 2); ++kc) {
             const f32x4 wa = *reinterpret_cast<const f32x4*>(Wp + frow * kSLD + kc * 16 + fk);
             f32x4 db[2];
 #pragma unroll
@@ -635,6 +639,8 @@ int launch_stem(StemParams p, hipStream_t st) {
     p.tiles_x = (p.W1 + kSTW - 1) / kSTW;
     const long tiles = (long)p.B * p.tiles_y * p.tiles_x;
     const long blocks = tiles < 512 ? tiles : 512;           // persistent: 2 workgroups per CU
+    static const int ablate = getenv("SSD_STEM_ABLATE") ? atoi(getenv("SSD_STEM_ABLATE")) : 0;
+    p.ablate = ablate;
     hipLaunchKernelGGL(mbv2_stem_kernel, dim3((unsigned)blocks), dim3(256), 0, st, p);
     SSD_LAUNCH_CHECK();
     return SSD_OK;
