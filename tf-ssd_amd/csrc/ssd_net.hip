@@ -65,7 +65,7 @@ struct Layer {
     float* splitk_part = nullptr;   // this layer's own split-K slab (layers may run concurrently)
     // LK_FUSED: weight copies with the folded BatchNorm scale multiplied in (per output channel)
     float *fz_we = nullptr, *fz_wd = nullptr, *fz_wp = nullptr;
-    int side = 0;                   // 1: runs on the side stream (SSD head convs)
+    int side = 0;                   // 1, 2: runs on that side stream (SSD head convs)
     hipEvent_t ev_ready = nullptr;  // recorded on the main stream when this layer's OUTPUT is complete
 };
 
@@ -115,8 +115,9 @@ struct ssd_net {
     // the head convs only depend on their feature map: they run on `side` concurrently with the
     // rest of the backbone / extras (fork after the producer, join before the softmax)
     bool overlap_heads = true;
-    hipStream_t side = nullptr;
-    hipEvent_t ev_side_done = nullptr;
+    static constexpr int kSides = 2;
+    hipStream_t side[kSides] = {nullptr, nullptr};
+    hipEvent_t ev_side_done[kSides] = {nullptr, nullptr};
     float* splitk_layers = nullptr;     // per-layer split-K slabs (post-autotune)
     bool timing = false;
     std::vector<std::vector<hipEvent_t>> timing_events;   // one vector of (layers + 2) events per forward
@@ -135,8 +136,10 @@ struct ssd_net {
             for (auto e : v) (void)hipEventDestroy(e);
         drop_graphs();
         if (gstream) (void)hipStreamDestroy(gstream);
-        if (side) (void)hipStreamDestroy(side);
-        if (ev_side_done) (void)hipEventDestroy(ev_side_done);
+        for (int k = 0; k < kSides; ++k) {
+            if (side[k]) (void)hipStreamDestroy(side[k]);
+            if (ev_side_done[k]) (void)hipEventDestroy(ev_side_done[k]);
+        }
         for (auto& l : layers)
             if (l.ev_ready) (void)hipEventDestroy(l.ev_ready);
         if (splitk_layers) (void)hipFree(splitk_layers);
@@ -291,7 +294,9 @@ struct Builder {
             l.head2_off = net.level_off[i] * 4;
             l.head2_bs = (long)net.num_priors * 4;
             l.head2_ps = (long)A * 4;
-            l.side = 1;
+            // the two large head convs share one side stream; the four small, launch-latency-bound
+            // ones get their own, so they run under the level-2 head instead of queueing behind it
+            l.side = i < 2 ? 1 : 2;
             net.layers.push_back(l);
         }
         Layer sm;
@@ -943,8 +948,10 @@ int ssd_net_finalize(ssd_net* net, int max_batch) {
                     o += align_up((size_t)l.split_k * max_batch * l.Ho * l.Wo * l.Cout, 64);
                 }
         }
-        if (!net->side) SSD_HIP(hipStreamCreateWithFlags(&net->side, hipStreamNonBlocking));
-        if (!net->ev_side_done) SSD_HIP(hipEventCreateWithFlags(&net->ev_side_done, hipEventDisableTiming));
+        for (int k = 0; k < ssd_net::kSides; ++k) {
+            if (!net->side[k]) SSD_HIP(hipStreamCreateWithFlags(&net->side[k], hipStreamNonBlocking));
+            if (!net->ev_side_done[k]) SSD_HIP(hipEventCreateWithFlags(&net->ev_side_done[k], hipEventDisableTiming));
+        }
         for (auto& l : net->layers)
             if (!l.ev_ready) SSD_HIP(hipEventCreateWithFlags(&l.ev_ready, hipEventDisableTiming));
     }
@@ -1010,30 +1017,40 @@ static int forward_impl(ssd_net* net, const float* image_dev, int B, float* delt
         for (auto& e : *ev) SSD_HIP(hipEventCreate(&e));
         (void)hipEventRecord((*ev)[0], st);
     }
-    const bool overlap = net->overlap_heads && !net->timing && net->side;
+    const bool overlap = net->overlap_heads && !net->timing && net->side[0];
     // which layers feed a side-stream layer (their completion must be published)
-    bool side_used = false;
+    bool side_used[ssd_net::kSides] = {false, false};
+    auto join_sides = [&]() -> int {
+        for (int k = 0; k < ssd_net::kSides; ++k)
+            if (side_used[k]) {
+                SSD_HIP(hipEventRecord(net->ev_side_done[k], net->side[k]));
+                SSD_HIP(hipStreamWaitEvent(st, net->ev_side_done[k], 0));
+                side_used[k] = false;
+            }
+        return SSD_OK;
+    };
     for (size_t i = 0; i < net->layers.size(); ++i) {
         Layer& l = net->layers[i];
         if (layer_runs(*net, l)) {
             if (overlap && l.side) {
+                const int k = l.side - 1;
+                hipStream_t ss = net->side[k];
                 // fork: the producer of this layer's input recorded ev_ready on the main stream
                 int prod = -1;
                 for (int j = (int)i - 1; j >= 0; --j)
                     if (net->layers[j].out == l.in && layer_runs(*net, net->layers[j])) { prod = j; break; }
-                if (prod >= 0) SSD_HIP(hipStreamWaitEvent(net->side, net->layers[prod].ev_ready, 0));
+                if (prod >= 0) SSD_HIP(hipStreamWaitEvent(ss, net->layers[prod].ev_ready, 0));
                 else {      // input produced before any layer (the image): order after current main work
                     SSD_HIP(hipEventRecord(l.ev_ready, st));
-                    SSD_HIP(hipStreamWaitEvent(net->side, l.ev_ready, 0));
+                    SSD_HIP(hipStreamWaitEvent(ss, l.ev_ready, 0));
                 }
-                const int rc = run_layer(*net, l, B, deltas_out, probs_out, net->side);
+                const int rc = run_layer(*net, l, B, deltas_out, probs_out, ss);
                 if (rc) return rc;
-                side_used = true;
+                side_used[k] = true;
             } else {
-                if (l.kind == LK_SOFTMAX && side_used) {        // join before the softmax
-                    SSD_HIP(hipEventRecord(net->ev_side_done, net->side));
-                    SSD_HIP(hipStreamWaitEvent(st, net->ev_side_done, 0));
-                    side_used = false;
+                if (l.kind == LK_SOFTMAX) {        // join before the softmax
+                    const int rcj = join_sides();
+                    if (rcj) return rcj;
                 }
                 const int rc = run_layer(*net, l, B, deltas_out, probs_out, st);
                 if (rc) return rc;
@@ -1048,9 +1065,9 @@ static int forward_impl(ssd_net* net, const float* image_dev, int B, float* delt
         }
         if (ev) (void)hipEventRecord((*ev)[i + 1], st);
     }
-    if (side_used) {    // no softmax layer after the side work: still join
-        SSD_HIP(hipEventRecord(net->ev_side_done, net->side));
-        SSD_HIP(hipStreamWaitEvent(st, net->ev_side_done, 0));
+    {   // no softmax layer after the side work: still join
+        const int rcj = join_sides();
+        if (rcj) return rcj;
     }
     net->last_batch = B;
     return SSD_OK;
