@@ -1,0 +1,1 @@
+"""Host-side mirrors of the reference's ``utils`` package (bbox / train / io / data / eval helpers) on top of libssd_hip."""

@@ -1,100 +1,92 @@
-"""Drop-in for the reference's ``utils/eval_utils.py`` (VOC2007 11-point mAP; SURVEY.md 8f
-row N2).  The pairwise IoU runs on the GPU (``bbox_utils.generate_iou_map``); the per-image
-bookkeeping is host NumPy, with the reference's quirks kept (see docstrings)."""
+"""Host-side mirror of the reference's ``utils/eval_utils.py`` (VOC2007 11-point mAP; SURVEY.md
+8f row N2): same function names, arguments and ``stats`` layout.  The pairwise IoU runs on the
+GPU (``bbox_utils.generate_iou_map`` -> ``ssd_iou_map``); the bookkeeping is host NumPy and keeps
+the reference's quirks, which the docstrings name.  Cited line numbers are the reference's."""
 import numpy as np
 
 from utils import bbox_utils
 
-
-def init_stats(labels):
-    """reference utils/eval_utils.py:5-17."""
-    stats = {}
-    for i, label in enumerate(labels):
-        if i == 0:
-            continue
-        stats[i] = {"label": label, "total": 0, "tp": [], "fp": [], "scores": []}
-    return stats
+_IOU_TP = 0.5
+_RECALL_POINTS = np.linspace(0.0, 1.0, 11)
 
 
-def _np(x):
+def _host(x):
     return x.detach().cpu().numpy() if hasattr(x, "detach") else np.asarray(x)
 
 
+def init_stats(labels):
+    """One record per foreground class id (index 0, the background, is skipped):
+    ``{"label", "total", "tp", "fp", "scores"}`` (utils/eval_utils.py:5-17)."""
+    return {cid: {"label": name, "total": 0, "tp": [], "fp": [], "scores": []}
+            for cid, name in enumerate(labels) if cid != 0}
+
+
 def update_stats(pred_bboxes, pred_labels, pred_scores, gt_boxes, gt_labels, stats):
-    """reference utils/eval_utils.py:19-54.  Predictions are visited in descending-IoU order
-    (not score order, :23,33); label 0 rows are padding (:35-36); a prediction is a TP iff
-    IoU >= 0.5, labels match and that GT index was not used before (:46-48)."""
-    iou_map = _np(bbox_utils.generate_iou_map(pred_bboxes, gt_boxes))          # [B, T, G]
-    pred_labels, pred_scores, gt_labels = _np(pred_labels), _np(pred_scores), _np(gt_labels)
-    merged = iou_map.max(-1)
-    max_idx = iou_map.argmax(-1)
-    sorted_ids = np.argsort(-merged, axis=-1, kind="stable")
-    uniq, counts = np.unique(gt_labels.reshape(-1), return_counts=True)
-    for lab, cnt in zip(uniq, counts):
-        if lab == -1:
-            continue
-        stats[int(lab)]["total"] += int(cnt)
-    for b in range(merged.shape[0]):
-        used = []
-        for sid in sorted_ids[b]:
-            pl = pred_labels[b, sid]
-            if pl == 0:
+    """utils/eval_utils.py:19-54.  Quirks kept: detections of an image are visited in descending
+    best-IoU order, not score order (:23,33); label 0 marks padding and is skipped (:35-36); a
+    detection is a true positive iff best IoU >= 0.5, its label equals the label of that
+    ground-truth box, and that box was not matched earlier (:46-48); ground-truth label -1
+    is padding and not counted (:27-31)."""
+    iou = _host(bbox_utils.generate_iou_map(pred_bboxes, gt_boxes))          # [B, T, G]
+    det_label, det_score, gt_label = _host(pred_labels), _host(pred_scores), _host(gt_labels)
+    for cid, n in zip(*np.unique(gt_label.ravel(), return_counts=True)):
+        if cid != -1:
+            stats[int(cid)]["total"] += int(n)
+    best_iou, best_gt = iou.max(axis=2), iou.argmax(axis=2)
+    visit = np.argsort(-best_iou, axis=1, kind="stable")
+    for img in range(best_iou.shape[0]):
+        taken = set()
+        for t in visit[img]:
+            cid = int(det_label[img, t])
+            if cid == 0:
                 continue
-            iou = merged[b, sid]
-            gt_id = int(max_idx[b, sid])
-            gl = int(gt_labels[b, gt_id])
-            pl = int(pl)
-            st = stats[pl]
-            st["scores"].append(pred_scores[b, sid])
-            st["tp"].append(0)
-            st["fp"].append(0)
-            if iou >= 0.5 and pl == gl and gt_id not in used:
-                st["tp"][-1] = 1
-                used.append(gt_id)
-            else:
-                st["fp"][-1] = 1
+            g = int(best_gt[img, t])
+            hit = best_iou[img, t] >= _IOU_TP and cid == int(gt_label[img, g]) and g not in taken
+            if hit:
+                taken.add(g)
+            rec = stats[cid]
+            rec["scores"].append(det_score[img, t])
+            rec["tp"].append(1 if hit else 0)
+            rec["fp"].append(0 if hit else 1)
     return stats
 
 
 def calculate_ap(recall, precision):
-    """reference utils/eval_utils.py:56-64 (11-point interpolation)."""
-    ap = 0
-    for r in np.arange(0, 1.1, 0.1):
-        prec_rec = precision[recall >= r]
-        if len(prec_rec) > 0:
-            ap += np.amax(prec_rec)
-    ap /= 11
-    return ap
+    """11-point interpolated AP: mean over r in {0, 0.1, .., 1} of the best precision at
+    recall >= r, 0 where no such point exists (utils/eval_utils.py:56-64)."""
+    recall, precision = np.asarray(recall), np.asarray(precision)
+    total = 0.0
+    for r in _RECALL_POINTS:
+        reachable = precision[recall >= r]
+        if reachable.size:
+            total += float(np.amax(reachable))
+    return total / len(_RECALL_POINTS)
 
 
 def calculate_mAP(stats):
-    """reference utils/eval_utils.py:66-85 (a class with no GT/predictions yields NaN, as there)."""
-    aps = []
-    for label in stats:
-        s = stats[label]
-        tp, fp, scores = np.array(s["tp"]), np.array(s["fp"]), np.array(s["scores"])
-        ids = np.argsort(-scores)
-        total = s["total"]
-        acc_tp = np.cumsum(tp[ids]) if len(ids) else np.array([])
-        acc_fp = np.cumsum(fp[ids]) if len(ids) else np.array([])
+    """Per class: sort by score, cumulate TP/FP, recall = TP / total, precision = TP / (TP + FP);
+    returns ``(stats, mean AP)`` with ``recall``/``precision``/``AP`` added to every record
+    (utils/eval_utils.py:66-85; a class without ground truth divides by zero exactly as there)."""
+    per_class = []
+    for rec in stats.values():
+        order = np.argsort(-np.asarray(rec["scores"], dtype=np.float64))
+        tp = np.cumsum(np.asarray(rec["tp"])[order]) if order.size else np.zeros(0)
+        fp = np.cumsum(np.asarray(rec["fp"])[order]) if order.size else np.zeros(0)
         with np.errstate(divide="ignore", invalid="ignore"):
-            recall = acc_tp / total
-            precision = acc_tp / (acc_fp + acc_tp)
-        ap = calculate_ap(recall, precision)
-        s["recall"], s["precision"], s["AP"] = recall, precision, ap
-        aps.append(ap)
-    return stats, np.mean(aps)
+            rec["recall"] = tp / rec["total"]
+            rec["precision"] = tp / (tp + fp)
+        rec["AP"] = calculate_ap(rec["recall"], rec["precision"])
+        per_class.append(rec["AP"])
+    return stats, np.mean(per_class)
 
 
 def evaluate_predictions(dataset, pred_bboxes, pred_labels, pred_scores, labels, batch_size):
-    """reference utils/eval_utils.py:87-97."""
+    """Walks ``dataset`` (batches of ``(images, gt_boxes, gt_labels)``) alongside the prediction
+    arrays, prints ``mAP: <value>`` and returns the stats (utils/eval_utils.py:87-97)."""
     stats = init_stats(labels)
-    for batch_id, image_data in enumerate(dataset):
-        imgs, gt_boxes, gt_labels = image_data
-        start = batch_id * batch_size
-        end = start + batch_size
-        stats = update_stats(pred_bboxes[start:end], pred_labels[start:end], pred_scores[start:end],
-                             gt_boxes, gt_labels, stats)
-    stats, mAP = calculate_mAP(stats)
-    print("mAP: {}".format(float(mAP)))
+    for i, (_, gt_boxes, gt_labels) in enumerate(dataset):
+        rows = slice(i * batch_size, (i + 1) * batch_size)
+        update_stats(pred_bboxes[rows], pred_labels[rows], pred_scores[rows], gt_boxes, gt_labels, stats)
+    stats, mean_ap = calculate_mAP(stats)
+    print("mAP: {}".format(float(mean_ap)))
     return stats

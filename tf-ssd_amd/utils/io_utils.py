@@ -1,47 +1,49 @@
-"""Drop-in for the reference's ``utils/io_utils.py`` (same flags, paths and asserts)."""
+"""Host-side mirror of the reference's ``utils/io_utils.py``: same function names, CLI flags,
+directory layout and failure modes, so ``trainer.py`` / ``predictor.py`` callers are unchanged.
+Cited line numbers are the reference's."""
 import argparse
 import os
-from datetime import datetime
+import time
+
+BACKBONES = ("mobilenet_v2", "vgg16")
+_WEIGHTS_DIR = "trained"
 
 
 def get_log_path(model_type, custom_postfix=""):
-    """reference utils/io_utils.py:6-15."""
-    return "logs/{}{}/{}".format(model_type, custom_postfix, datetime.now().strftime("%Y%m%d-%H%M%S"))
+    """``logs/<model_type><postfix>/<YYYYmmdd-HHMMSS>`` (utils/io_utils.py:6-15)."""
+    stamp = time.strftime("%Y%m%d-%H%M%S", time.localtime())
+    return "/".join(("logs", "%s%s" % (model_type, custom_postfix), stamp))
 
 
 def get_model_path(model_type):
-    """reference utils/io_utils.py:17-29.  The weights container here is a NumPy ``.npz``
-    keyed by the Keras variable names (h5py is not available); the reference's ``.h5``
-    suffix is kept so callers see the same path."""
-    main_path = "trained"
-    if not os.path.exists(main_path):
-        os.makedirs(main_path)
-    model_path = os.path.join(main_path, "ssd_{}_model_weights.h5".format(model_type))
-    return model_path
+    """``trained/ssd_<model_type>_model_weights.h5`` and make sure the directory exists
+    (utils/io_utils.py:17-29).  The container written under that name is a NumPy ``.npz`` keyed
+    by the Keras variable names -- h5py is not available -- but the reference's file name is
+    kept so that scripts and callers see the same path."""
+    os.makedirs(_WEIGHTS_DIR, exist_ok=True)
+    return os.path.join(_WEIGHTS_DIR, "ssd_%s_model_weights.h5" % model_type)
 
 
 def handle_args(argv=None):
-    """reference utils/io_utils.py:31-44."""
-    parser = argparse.ArgumentParser(description="SSD: Single Shot MultiBox Detector Implementation")
-    parser.add_argument("-handle-gpu", action="store_true", help="GPU compatibility flag (selects/probes the HIP device)")
-    parser.add_argument("--backbone", required=False,
-                        default="mobilenet_v2",
-                        metavar="['mobilenet_v2', 'vgg16']",
-                        help="Which backbone used for the ssd")
-    args = parser.parse_args(argv)
-    return args
+    """The reference's two flags: ``-handle-gpu`` and ``--backbone`` (utils/io_utils.py:31-44)."""
+    cli = argparse.ArgumentParser(description="SSD: Single Shot MultiBox Detector Implementation")
+    cli.add_argument("-handle-gpu", action="store_true",
+                     help="GPU compatibility flag (selects/probes the HIP device)")
+    cli.add_argument("--backbone", default=BACKBONES[0], required=False, metavar=str(list(BACKBONES)),
+                     help="Which backbone used for the ssd")
+    return cli.parse_args(argv)
 
 
 def is_valid_backbone(backbone):
-    """reference utils/io_utils.py:46-52."""
-    assert backbone in ["mobilenet_v2", "vgg16"]
+    """AssertionError for anything but the two supported backbones (utils/io_utils.py:46-52)."""
+    assert backbone in BACKBONES
 
 
 def handle_gpu_compatibility():
-    """reference utils/io_utils.py:54-61: the reference toggles TF memory growth; here it
-    initialises the HIP device of this process and prints (not raises) any failure."""
+    """The reference switches TF memory growth on and prints any failure
+    (utils/io_utils.py:54-61); the equivalent here is initialising this process's HIP device."""
     try:
         import ssd_hip
         ssd_hip.device()
-    except Exception as e:
-        print(e)
+    except Exception as exc:      # printed, not raised: same contract as the reference
+        print(exc)

@@ -8,67 +8,49 @@ import torch
 import ssd_hip as _h
 from utils import bbox_utils
 
-# reference utils/train_utils.py:5-26 (verbatim configuration values)
-SSD = {
-    "vgg16": {
-        "img_size": 300,
-        "feature_map_shapes": [38, 19, 10, 5, 3, 1],
-        "aspect_ratios": [[1., 2., 1./2.],
-                         [1., 2., 1./2., 3., 1./3.],
-                         [1., 2., 1./2., 3., 1./3.],
-                         [1., 2., 1./2., 3., 1./3.],
-                         [1., 2., 1./2.],
-                         [1., 2., 1./2.]],
-    },
-    "mobilenet_v2": {
-        "img_size": 300,
-        "feature_map_shapes": [19, 10, 5, 3, 2, 1],
-        "aspect_ratios": [[1., 2., 1./2.],
-                         [1., 2., 1./2., 3., 1./3.],
-                         [1., 2., 1./2., 3., 1./3.],
-                         [1., 2., 1./2., 3., 1./3.],
-                         [1., 2., 1./2.],
-                         [1., 2., 1./2.]],
-    }
-}
+# Configuration values of the reference (utils/train_utils.py:5-26): SSD300 with six feature
+# maps; levels 2-4 use five aspect ratios (4 + 2 = 6 anchors), the others three (2 + 2 = 4).
+_R3 = (1.0, 2.0, 1.0 / 2.0)
+_R5 = _R3 + (3.0, 1.0 / 3.0)
+_LEVEL_RATIOS = (_R3, _R5, _R5, _R5, _R3, _R3)
+_FEATURE_MAPS = {"vgg16": (38, 19, 10, 5, 3, 1), "mobilenet_v2": (19, 10, 5, 3, 2, 1)}
+SSD = {name: {"img_size": 300, "feature_map_shapes": list(fm), "aspect_ratios": [list(r) for r in _LEVEL_RATIOS]}
+       for name, fm in _FEATURE_MAPS.items()}
+
+_FIXED = (("iou_threshold", 0.5), ("neg_pos_ratio", 3), ("loc_loss_alpha", 1), ("variances", [0.1, 0.1, 0.2, 0.2]))
+_LR_STEPS = ((100, 1e-3), (125, 1e-4))      # (first epoch NOT covered, learning rate)
 
 
 def get_hyper_params(backbone, **kwargs):
-    """reference utils/train_utils.py:28-45: returns (and mutates) the global table entry;
-    kwargs override only keys that already exist and only with truthy values."""
-    hyper_params = SSD[backbone]
-    hyper_params["iou_threshold"] = 0.5
-    hyper_params["neg_pos_ratio"] = 3
-    hyper_params["loc_loss_alpha"] = 1
-    hyper_params["variances"] = [0.1, 0.1, 0.2, 0.2]
-    for key, value in kwargs.items():
-        if key in hyper_params and value:
-            hyper_params[key] = value
-    return hyper_params
+    """The table entry of ``backbone`` plus the fixed training/inference constants
+    (utils/train_utils.py:28-45).  As in the reference the returned dict IS the module-level
+    entry (later mutations are visible to every holder), and a keyword only overrides a key
+    that already exists, and only with a truthy value."""
+    hp = SSD[backbone]
+    hp.update((k, list(v) if isinstance(v, list) else v) for k, v in _FIXED)
+    hp.update({k: v for k, v in kwargs.items() if k in hp and v})
+    return hp
 
 
 def scheduler(epoch):
-    """reference utils/train_utils.py:47-60."""
-    if epoch < 100:
-        return 1e-3
-    elif epoch < 125:
-        return 1e-4
-    else:
-        return 1e-5
+    """1e-3 below epoch 100, 1e-4 below 125, 1e-5 afterwards (utils/train_utils.py:47-60)."""
+    for end, lr in _LR_STEPS:
+        if epoch < end:
+            return lr
+    return 1e-5
 
 
 def get_step_size(total_items, batch_size):
-    """reference utils/train_utils.py:62-71."""
+    """ceil(total_items / batch_size) (utils/train_utils.py:62-71)."""
     return math.ceil(total_items / batch_size)
 
 
 def generator(dataset, prior_boxes, hyper_params):
-    """reference utils/train_utils.py:73-88: endless (img, (deltas, labels)) generator."""
+    """Endless ``(img, (bbox_deltas, bbox_labels))`` stream for ``model.fit``: every pass over
+    ``dataset`` re-encodes the ground truth against the priors (utils/train_utils.py:73-88)."""
     while True:
-        for image_data in dataset:
-            img, gt_boxes, gt_labels = image_data
-            actual_deltas, actual_labels = calculate_actual_outputs(prior_boxes, gt_boxes, gt_labels, hyper_params)
-            yield img, (actual_deltas, actual_labels)
+        for img, gt_boxes, gt_labels in dataset:
+            yield img, calculate_actual_outputs(prior_boxes, gt_boxes, gt_labels, hyper_params)
 
 
 def calculate_actual_outputs(prior_boxes, gt_boxes, gt_labels, hyper_params, return_indices=False):
