@@ -32,7 +32,10 @@ namespace {
 
 constexpr int kCK = 48;           // expanded channels per chunk (divides 384, 576, 960)
 constexpr int kCQ = kCK / 4;      // channel quads per chunk
-constexpr int kLD = kCK + 4;      // LDS row stride (floats) of the E / D / Wp tiles
+// LDS row stride (floats) of the E / D / Wp tiles: 14 quads make the b128 MFMA fragment reads
+// conflict-free under gfx950's lane grouping (13 quads are 2-way conflicted); the stride-2
+// shape keeps 13 so that its double-buffered tiles still fit the 160 KB of LDS.
+constexpr int ld_for(int stride) { return stride == 2 ? kCK + 4 : kCK + 8; }
 
 __device__ __forceinline__ float relu6f(float v) { return fminf(fmaxf(v, 0.0f), 6.0f); }
 
@@ -64,7 +67,8 @@ struct DwProjShape {
     static constexpr int NSX = (TW + SL - 1) / SL;                  // strips per output row
     static constexpr int STRIPS = TH * NSX;
     static constexpr int WIN = (SL - 1) * S + 3;                    // input columns a strip needs
-    static constexpr size_t lds_floats = (size_t)HP * kLD + (size_t)PG * 16 * kLD + (size_t)NTB * 16 * kLD + 10 * kCK;
+    static constexpr int LD = ld_for(S);
+    static constexpr size_t lds_floats = (size_t)HP * LD + (size_t)PG * 16 * LD + (size_t)NTB * 16 * LD + 10 * kCK;
     static_assert(WM * WN == 4, "4 waves");
     static_assert(STRIPS * kCQ <= 256, "depthwise mapping needs STRIPS * 12 <= 256 threads");
 };
@@ -72,7 +76,7 @@ struct DwProjShape {
 template <int S, int TH, int TW, int SL, int WM, int WN, int NTW>
 __global__ __launch_bounds__(256) void dwproj_kernel(const DwProjParams p) {
     using Sh = DwProjShape<S, TH, TW, SL, WM, WN, NTW>;
-    constexpr int PT = Sh::PT, PG = Sh::PG, MTW = Sh::MTW, NTB = Sh::NTB, IW = Sh::IW, HP = Sh::HP;
+    constexpr int PT = Sh::PT, PG = Sh::PG, MTW = Sh::MTW, NTB = Sh::NTB, IW = Sh::IW, HP = Sh::HP, kLD = Sh::LD;
     extern __shared__ __attribute__((aligned(16))) float sm[];
     float* Es = sm;                                  // [HP][kLD]
     float* Ds = Es + HP * kLD;                       // [PG*16][kLD]
@@ -256,7 +260,7 @@ __global__ __launch_bounds__(256) void dwproj_kernel(const DwProjParams p) {
 template <int S, int TH, int TW, int SL, int WM, int WN, int NTW, int NOPS>
 __global__ __launch_bounds__(512) void dwproj8_kernel(const DwProjParams p) {
     using Sh = DwProjShape<S, TH, TW, SL, WM, WN, NTW>;
-    constexpr int PT = Sh::PT, PG = Sh::PG, MTW = Sh::MTW, NTB = Sh::NTB, IW = Sh::IW, HP = Sh::HP;
+    constexpr int PT = Sh::PT, PG = Sh::PG, MTW = Sh::MTW, NTB = Sh::NTB, IW = Sh::IW, HP = Sh::HP, kLD = Sh::LD;
     constexpr int ES = HP * kLD, DS = PG * 16 * kLD, WS = NTB * 16 * kLD, WD = 10 * kCK;
     extern __shared__ __attribute__((aligned(16))) float sm[];
     float* Es = sm;                  // [2][HP][kLD]

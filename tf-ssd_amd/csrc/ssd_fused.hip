@@ -56,7 +56,13 @@ __device__ __forceinline__ void wait_prefetch(f32x4 (&r)[N]) {
 }
 
 constexpr int kCK = 48;          // expanded channels per chunk
-constexpr int kLDE = kCK + 4;    // LDS row stride of E / D / Wp chunk tiles
+// LDS row strides.  A b128 access of 16 rows x 4 column groups (MFMA fragments, accumulator-layout
+// tile writes) is conflict-free under gfx950's lane grouping when the stride is 2 (mod 4) quads:
+// 56 floats for the E / D / Wp chunk tiles (52 was 2-way conflicted), 24 for Cin 16 / 24 X tiles.
+// Cin = 32 keeps 36 (9 quads, conflicted): 40 would push blocks 4/5 past 80 KB, i.e. to one
+// workgroup per CU.
+constexpr int kLDE = kCK + 8;
+constexpr int ldx_for(int cinp) { return cinp <= 24 ? 24 : cinp + 4; }
 
 // Expand NP (1 or 2) halo-pixel tiles of 16 pixels against the 48-channel weight chunk:
 // 3*NP independent accumulator chains keep the fp32 MFMA pipe issuing back to back.
@@ -65,7 +71,7 @@ __device__ __forceinline__ void expand_px_tiles(const float* Xs, const float* We
                                                 const int Ce, const int ce0, const int pt0, const int pt1,
                                                 const int lane, const int iy0, const int ix0, const int H,
                                                 const int W, const int ablate = 0) {
-    constexpr int LDX = CINP + 4;
+    constexpr int LDX = ldx_for(CINP);
     const int frow = lane & 15, fk = (lane >> 4) * 4;
     const int pts[2] = {pt0, pt1};
     // accumulators start at the folded BatchNorm shift (the scale is folded into the weights)
@@ -148,7 +154,7 @@ __global__ __launch_bounds__(256, 2) void mbv2_block_kernel(const FusedBlockPara
     constexpr int WPX = OPX / 16;                   // waves along pixels in phase C
     constexpr int WN = 4 / WPX;                     // waves along output channels
     constexpr int NTW = NTC / WN;                   // n-tiles per wave
-    constexpr int LDX = CINP + 4;
+    constexpr int LDX = ldx_for(CINP);
     static_assert(OPX % 16 == 0 && 4 % WPX == 0 && NTC % WN == 0, "tile split");
     constexpr int WE_U = kCK * CINP / 4, WP_U = NTC * 16 * kCK / 4;       // float4 units per chunk
     constexpr int WE_R = (WE_U + 255) / 256, WP_R = (WP_U + 255) / 256;
@@ -402,7 +408,7 @@ template <int CINP, int NTC, int S, int TH, int TW>
 constexpr size_t fused_static_floats() {
     constexpr int IH = (TH - 1) * S + 3, IW = (TW - 1) * S + 3;
     constexpr int IPXP = (IH * IW + 15) / 16 * 16;
-    return (size_t)IPXP * (CINP + 4) + (size_t)IPXP * kLDE + (size_t)TH * TW * kLDE + (size_t)kCK * (CINP + 4) +
+    return (size_t)IPXP * ldx_for(CINP) + (size_t)IPXP * kLDE + (size_t)TH * TW * kLDE + (size_t)kCK * ldx_for(CINP) +
            (size_t)NTC * 16 * kLDE;
 }
 
