@@ -490,7 +490,7 @@ int launch_fused_block(FusedBlockParams p, hipStream_t st) {
 constexpr int kSTH = 8, kSTW = 16;
 constexpr int kSIH = kSTH + 2, kSIW = kSTW + 2;           // Conv1 halo tile 10 x 18
 constexpr int kSPH = 2 * (kSIH - 1) + 3, kSPW = 2 * (kSIW - 1) + 3;   // image patch 21 x 37
-constexpr int kSLD = 36;                                  // LDS row stride of the 32-channel tiles
+constexpr int kSLD = 40;                                  // LDS row stride of the 32-channel tiles (10 quads: conflict-free b128 fragment reads)
 
 __global__ __launch_bounds__(256) void mbv2_stem_kernel(const StemParams p) {
     __shared__ __attribute__((aligned(16))) float sm[kSPH * kSPW * 3 + 5 + kSIH * kSIW * kSLD + kSTH * kSTW * kSLD +
