@@ -70,7 +70,20 @@ for tag, counter in (("pmc_fetch", "FETCH_SIZE"), ("pmc_write", "WRITE_SIZE")):
 if traffic and os.environ.get("TRAFFIC_JSON"):
     import json
     with open(os.environ["TRAFFIC_JSON"], "w") as fh:
-        json.dump({"source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) of `python bench.py --steps 10 "
+        import hashlib
+        import subprocess
+        repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+        hh = hashlib.sha256()
+        for f in sorted(glob.glob(os.path.join(repo, "tf-ssd_amd", "csrc", "*.hip")) +
+                        glob.glob(os.path.join(repo, "tf-ssd_amd", "csrc", "*.h"))):
+            hh.update(open(f, "rb").read())
+        try:
+            commit = subprocess.check_output(["git", "-C", repo, "rev-parse", "--short", "HEAD"],
+                                             stderr=subprocess.DEVNULL).decode().strip()
+        except Exception:
+            commit = os.environ.get("SSD_COMMIT")       # no .git on the GPU box: collect.sh passes it
+        json.dump({"commit": commit, "kernel_sources_sha16": hh.hexdigest()[:16],
+                   "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) of `python bench.py --steps 10 "
                              "--warmup 3 --no-cpu-baseline`, summed per kernel family over the whole process",
                    "note": "FETCH_SIZE on gfx950 reports 1/2 of wide (16 B/lane) coalesced reads: double it "
                            "(MI355X_MICROARCH.md, HBM section); Infinity-Cache hits are counted",

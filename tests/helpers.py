@@ -89,16 +89,27 @@ def synthetic_weights(backbone, hp=None, seed=1, target_frac=0.05):
     no.forward(backbone, hp, w, images(1, hp["img_size"], seed=0), acts)
     logits = acts["labels_head"][0].astype(np.float64)            # [N, L]
 
-    def frac(t):
-        lg = logits.copy()
+    def frac(t, g=1.0):
+        lg = logits * g
         lg[:, 0] += t
         e = np.exp(lg - lg.max(-1, keepdims=True))
         p = e / e.sum(-1, keepdims=True)
         return float(((p.argmax(-1) != 0) & (p.max(-1) > 0.5)).mean())
-    lo, hi = -50.0, 50.0
+    # the class spread of the random label heads must allow a single class to exceed 0.5 at all
+    # (VGG16: logit std 0.55 -> never, whatever the background bias): scale label kernels AND biases
+    # by g (the conv is linear: logits scale by g exactly) until, background removed, at least
+    # 3 x target_frac of the anchors qualify.  MobileNetV2 keeps g = 1.
+    g = 1.0
+    while frac(-1e4, g) < 3 * target_frac and g < 64:
+        g *= 2.0
+    if g != 1.0:
+        for i in range(1, 7):
+            w["%d_conv_label_output/kernel" % i] *= np.float32(g)
+            w["%d_conv_label_output/bias" % i] *= np.float32(g)
+    lo, hi = -50.0 * g, 50.0 * g
     for _ in range(40):
         mid = 0.5 * (lo + hi)
-        if frac(mid) > target_frac:
+        if frac(mid, g) > target_frac:
             lo = mid
         else:
             hi = mid
@@ -107,3 +118,59 @@ def synthetic_weights(backbone, hp=None, seed=1, target_frac=0.05):
         w["%d_conv_label_output/bias" % i][0::L] += t
     _WCACHE[key] = w
     return w
+
+
+# --------------------------------------------------------------------------------------------
+# External known answers ([3P], written down FROM MEMORY of TensorFlow's own unit tests -- TF is
+# not installable here, so they could not be re-executed; they do not come from this repo's
+# oracle): tensorflow/core/kernels/non_max_suppression_op_test.cc (NonMaxSuppressionOpTest /
+# CombinedNonMaxSuppressionOpTest) and python/ops/image_ops_test.py (NonMaxSuppressionTest).
+# Each case: boxes [N,4], scores [N,C], max_per_class, max_total, iou_thr, score_thr, clip ->
+# expected kept anchor indices (in output order), classes, valid.
+_TF_THREE_CLUSTERS = [[0, 0, 1, 1], [0, 0.1, 1, 1.1], [0, -0.1, 1, 0.9],
+                      [0, 10, 1, 11], [0, 10.1, 1, 11.1], [0, 100, 1, 101]]
+_TF_THREE_CLUSTERS_FLIPPED = [[1, 1, 0, 0], [0, 0.1, 1, 1.1], [0, .9, 1, -0.1],
+                              [0, 10, 1, 11], [1, 10.1, 0, 11.1], [1, 101, 0, 100]]
+_TF_SCORES6 = [.9, .75, .6, .95, .5, .3]
+_TF_COMBINED_BOXES = [[0, 0, 0.1, 0.1], [0, 0.01, 0.1, 0.11], [0, -0.01, 0.1, 0.09],
+                      [0, 0.11, 0.1, 0.2], [0, 0.12, 0.1, 0.21], [0, 0.3, 1, 0.4]]
+
+
+def tf_nms_known_answers():
+    f = np.float32
+    col = lambda s: np.asarray(s, f).reshape(-1, 1)
+    cases = [
+        # NonMaxSuppressionOpTest.TestSelectFromThreeClusters -> [3, 0, 5]
+        dict(name="three_clusters", boxes=_TF_THREE_CLUSTERS, scores=col(_TF_SCORES6), mpc=3, mt=3,
+             iou=0.5, thr=float("-inf"), clip=False, idx=[3, 0, 5], cls=[0, 0, 0]),
+        # ...FlippedCoordinates -> [3, 0, 5] (corners are re-ordered inside the IoU)
+        dict(name="three_clusters_flipped", boxes=_TF_THREE_CLUSTERS_FLIPPED, scores=col(_TF_SCORES6), mpc=3,
+             mt=3, iou=0.5, thr=float("-inf"), clip=False, idx=[3, 0, 5], cls=[0, 0, 0]),
+        # TestSelectAtMostTwoBoxesFromThreeClusters -> [3, 0]
+        dict(name="at_most_two", boxes=_TF_THREE_CLUSTERS, scores=col(_TF_SCORES6), mpc=2, mt=2, iou=0.5,
+             thr=float("-inf"), clip=False, idx=[3, 0], cls=[0, 0]),
+        # TestSelectWithNegativeScores (scores - 10) -> [3, 0, 5]
+        dict(name="negative_scores", boxes=_TF_THREE_CLUSTERS, scores=col(_TF_SCORES6) - f(10), mpc=6, mt=6,
+             iou=0.5, thr=float("-inf"), clip=False, idx=[3, 0, 5], cls=[0, 0, 0]),
+        # TestSelectFromTenIdenticalBoxes -> [0]
+        dict(name="ten_identical", boxes=[[0, 0, 1, 1]] * 10, scores=col([.9] * 10), mpc=3, mt=3, iou=0.5,
+             thr=float("-inf"), clip=False, idx=[0], cls=[0]),
+        # TestSelectSingleBox -> [0]
+        dict(name="single_box", boxes=[[0, 0, 1, 1]], scores=col([.9]), mpc=3, mt=3, iou=0.5,
+             thr=float("-inf"), clip=False, idx=[0], cls=[0]),
+        # CombinedNonMaxSuppressionOpTest.TestSelectFromThreeClusters: boxes {0,.11,.1,.2},{0,0,.1,.1},
+        # {0,.3,1,.4}; scores {.95,.9,.3}; valid 3
+        dict(name="combined_three_clusters", boxes=_TF_COMBINED_BOXES, scores=col(_TF_SCORES6), mpc=3, mt=3,
+             iou=0.5, thr=0.0, clip=True, idx=[3, 0, 5], cls=[0, 0, 0]),
+        # ...WithScoreThreshold (0.4): third row zero padded, valid 2
+        dict(name="combined_score_threshold", boxes=_TF_COMBINED_BOXES, scores=col(_TF_SCORES6), mpc=3, mt=3,
+             iou=0.5, thr=0.4, clip=True, idx=[3, 0], cls=[0, 0]),
+        # ...WithTwoClasses: boxes {0,.11,.1,.2},{0,0,.1,.1},{0,.01,.1,.11}; classes {0,1,0}
+        dict(name="combined_two_classes", boxes=_TF_COMBINED_BOXES,
+             scores=np.asarray([[.1, .9], [.75, .8], [.6, .3], [.95, .1], [.5, .5], [.3, .1]], f), mpc=3, mt=3,
+             iou=0.5, thr=0.0, clip=True, idx=[3, 0, 1], cls=[0, 1, 0]),
+    ]
+    for c in cases:
+        c["boxes"] = np.asarray(c["boxes"], f)
+        c["scores"] = np.asarray(c["scores"], f)
+    return cases

@@ -147,6 +147,38 @@ def test_combined_nms_raw(bbox_utils):
         bbox_utils.non_max_suppression(boxes[:, :, None, :], scores)
 
 
+def test_tf_published_nms_known_answers_gpu(bbox_utils):
+    """TensorFlow's own NMS unit-test vectors ([3P], from memory: helpers.tf_nms_known_answers)
+    through the product's ssd_combined_nms -- known answers that do not come from this repo."""
+    import ssd_hip as h
+    lib = h.lib()
+    for c in helpers.tf_nms_known_answers():
+        N, C = c["scores"].shape
+        T = c["mt"]
+        bd, sd = h.to_dev(c["boxes"][None]), h.to_dev(c["scores"][None])
+        ob = torch.empty((1, T, 4), dtype=torch.float32, device=bd.device)
+        os_ = torch.empty((1, T), dtype=torch.float32, device=bd.device)
+        oc = torch.empty((1, T), dtype=torch.float32, device=bd.device)
+        ov = torch.empty((1,), dtype=torch.int32, device=bd.device)
+        oi = torch.empty((1, T), dtype=torch.int32, device=bd.device)
+        ws = h.workspace(lib.ssd_decode_nms_workspace_bytes(1, N, C, c["mpc"]))
+        thr = c["thr"] if np.isfinite(c["thr"]) else -3.0e38
+        h.check(lib.ssd_combined_nms(h.ptr(bd), h.ptr(sd), 1, N, C, c["mpc"], T, c["iou"], thr, int(c["clip"]),
+                                     h.ptr(ob), h.ptr(os_), h.ptr(oc), h.ptr(ov), h.ptr(oi), h.ptr(ws), ws.numel(),
+                                     h.stream()), c["name"])
+        n = len(c["idx"])
+        assert int(ov[0]) == n, c["name"]
+        assert _np(oi)[0, :n].tolist() == c["idx"], c["name"]
+        assert _np(oi)[0, n:].tolist() == [-1] * (T - n), c["name"]
+        assert _np(oc)[0, :n].tolist() == c["cls"], c["name"]
+        exp_b = c["boxes"][c["idx"]]
+        if c["clip"]:
+            exp_b = np.clip(exp_b, 0, 1)
+        np.testing.assert_array_equal(_np(ob)[0, :n], exp_b)
+        np.testing.assert_array_equal(_np(os_)[0, :n], c["scores"][c["idx"], c["cls"]])
+        assert not _np(ob)[0, n:].any() and not _np(os_)[0, n:].any()
+
+
 def test_iou_map_and_match(bbox_utils):
     from utils import train_utils
     z = np.load(os.path.join(GOLD, "match.npz"))

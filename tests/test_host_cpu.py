@@ -170,3 +170,32 @@ def test_native_graph_matches_oracle_and_published_counts(backbone, n_priors):
     bad["feature_map_shapes"] = list(hp["feature_map_shapes"][:-1]) + [7]
     with pytest.raises(ValueError):
         SSDModel(backbone, bad)
+
+
+def test_u1_box_helpers_product_vs_oracle():
+    """normalize / denormalize / renormalize of the PRODUCT's utils.bbox_utils
+    (reference utils/bbox_utils.py:178-222) against the oracle and hand-computed answers,
+    incl. round-half-to-even and clipping."""
+    from utils import bbox_utils as bu
+    from oracle import bbox_oracle as bo
+    rng = np.random.default_rng(7)
+    b = np.array([[[10.5, 20.5, 30.5, 41.5]]], np.float32)
+    n = bu.normalize_bboxes(b, 100, 200).numpy()
+    np.testing.assert_allclose(n, [[[0.105, 0.1025, 0.305, 0.2075]]], rtol=1e-6)
+    d = bu.denormalize_bboxes(np.array([[[0.105, 0.1025, 0.305, 0.2075]]], np.float32), 100, 200).numpy()
+    np.testing.assert_array_equal(d, [[[10, 20, 30, 42]]])        # 10.5 -> 10, 20.5 -> 20: half to even
+    r = bu.renormalize_bboxes_with_min_max(np.array([[0.2, 0.2, 0.6, 1.2]], np.float32),
+                                           np.array([0.1, 0.1, 0.9, 0.9], np.float32)).numpy()
+    np.testing.assert_allclose(r, [[0.125, 0.125, 0.625, 1.0]], rtol=1e-6)
+    for shape in ((7, 4), (3, 5, 4), (2, 1, 9, 4)):
+        x = rng.uniform(-0.2, 1.2, shape).astype(np.float32)
+        for h, w in ((300, 300), (375, 500), (1, 7)):
+            np.testing.assert_array_equal(bu.denormalize_bboxes(x, h, w).numpy(), bo.denormalize_bboxes(x, h, w))
+            px = (x * np.float32(max(h, w))).astype(np.float32)
+            np.testing.assert_array_equal(bu.normalize_bboxes(px, h, w).numpy(), bo.normalize_bboxes(px, h, w))
+        mm = np.array([0.1, 0.2, 0.7, 0.9], np.float32)
+        np.testing.assert_array_equal(bu.renormalize_bboxes_with_min_max(x, mm).numpy(),
+                                      bo.renormalize_bboxes_with_min_max(x, mm))
+    # exact .5 products round to even in both directions
+    half = np.array([[0.5, 1.5, 2.5, 3.5]], np.float32)
+    np.testing.assert_array_equal(bu.denormalize_bboxes(half, 1, 1).numpy(), [[0, 2, 2, 4]])

@@ -147,3 +147,24 @@ def test_normalize_helpers():
     r = bo.renormalize_bboxes_with_min_max(np.array([[0.2, 0.2, 0.6, 1.2]], np.float32),
                                            np.array([0.1, 0.1, 0.9, 0.9], np.float32))
     np.testing.assert_allclose(r, [[0.125, 0.125, 0.625, 1.0]], rtol=1e-6)
+
+
+def test_tf_published_nms_known_answers():
+    """External anchors for the CombinedNMS restatement: the expected selections of TensorFlow's
+    own NMS unit tests ([3P], from memory -- see helpers.tf_nms_known_answers)."""
+    import helpers
+    for c in helpers.tf_nms_known_answers():
+        N = c["boxes"].shape[0]
+        b, s, k, v, idx = bo.combined_non_max_suppression(c["boxes"][None, :, None, :], c["scores"][None], c["mpc"],
+                                                          c["mt"], c["iou"], c["thr"], clip_boxes=c["clip"],
+                                                          return_indices=True)
+        n = len(c["idx"])
+        assert int(v[0]) == n, c["name"]
+        assert idx[0, :n].tolist() == c["idx"], c["name"]
+        assert k[0, :n].tolist() == c["cls"], c["name"]
+        exp_b = c["boxes"][c["idx"]]
+        if c["clip"]:
+            exp_b = np.clip(exp_b, 0, 1)
+        np.testing.assert_array_equal(b[0, :n], exp_b)
+        np.testing.assert_array_equal(s[0, :n], c["scores"][c["idx"], c["cls"]])
+        assert not b[0, n:].any() and not s[0, n:].any()       # zero padding rows

@@ -98,6 +98,7 @@ struct ssd_net {
     float* probs = nullptr;
     void* nms_ws = nullptr;
     size_t nms_ws_bytes = 0;
+    int scratch_batch = 0;          // batch capacity deltas/probs were allocated for
     // optional per-layer hipEvent timing of forward()/predict() (bench.py roofline leg)
     std::map<std::string, std::pair<std::string, int>> preset;   // layer -> (config name, split_k)
     // hipGraph replay of a whole forward/predict step, keyed by every pointer baked into it
@@ -106,6 +107,8 @@ struct ssd_net {
         std::vector<const void*> key;
         hipGraphExec_t exec = nullptr;
         hipGraph_t graph = nullptr;
+        const float* image = nullptr;   // restored on replay (fetch_activation / profile hooks read them)
+        int batch = 0;
     };
     std::vector<GraphEntry> graphs;
     // graphs cannot be captured on the legacy NULL stream (PyTorch's default stream): such
@@ -591,13 +594,25 @@ static int dev_alloc(ssd_net& net, size_t floats, float** out) {
 
 // Time each valid (tile configuration, split-K factor) of every conv layer on the device and
 // keep the best.  Split-K is tried only where the plain grid cannot fill the 256 CUs.
+// Scope guards: the SSD_HIP early returns of the tuning / profiling entry points must not leak
+struct ScopedDev {
+    float* p = nullptr;
+    ~ScopedDev() { if (p) (void)hipFree(p); }
+};
+struct ScopedEvent {
+    hipEvent_t e = nullptr;
+    ~ScopedEvent() { if (e) (void)hipEventDestroy(e); }
+};
+
 static int autotune(ssd_net& net, int B, hipStream_t st) {
-    hipEvent_t e0, e1;
-    SSD_HIP(hipEventCreate(&e0));
-    SSD_HIP(hipEventCreate(&e1));
-    float *d = nullptr, *pr = nullptr;     // scratch outputs for the head convs
-    SSD_HIP(hipMalloc((void**)&d, (size_t)B * net.num_priors * 4 * sizeof(float)));
-    SSD_HIP(hipMalloc((void**)&pr, (size_t)B * net.num_priors * net.L * sizeof(float)));
+    ScopedEvent se0, se1;
+    SSD_HIP(hipEventCreate(&se0.e));
+    SSD_HIP(hipEventCreate(&se1.e));
+    hipEvent_t e0 = se0.e, e1 = se1.e;
+    ScopedDev sd, spr;                     // scratch outputs for the head convs
+    SSD_HIP(hipMalloc((void**)&sd.p, (size_t)B * net.num_priors * 4 * sizeof(float)));
+    SSD_HIP(hipMalloc((void**)&spr.p, (size_t)B * net.num_priors * net.L * sizeof(float)));
+    float *d = sd.p, *pr = spr.p;
     // dense around small factors: the best split is the one whose M-blocks x split just fills a
     // whole number of CU rounds (e.g. 100 M-blocks x 5 = 500 blocks on 512 slots for head 2)
     static const int kSplits[] = {1, 2, 3, 4, 5, 6, 7, 8, 10, 12, 14, 16, 20, 24, 32};
@@ -669,10 +684,6 @@ static int autotune(ssd_net& net, int B, hipStream_t st) {
         l.cfg = best_cfg;
         l.split_k = best_split;
     }
-    (void)hipFree(d);
-    (void)hipFree(pr);
-    (void)hipEventDestroy(e0);
-    (void)hipEventDestroy(e1);
     return rc;
 }
 
@@ -695,6 +706,9 @@ static int run_graphed(ssd_net* net, std::vector<const void*> key, hipStream_t& 
     for (auto& g : net->graphs)
         if (g.key == key) {
             SSD_HIP(hipGraphLaunch(g.exec, st));
+            // the replay bypasses forward_impl: keep the debug/parity hooks' view of the last call
+            net->tensors[0].dev = const_cast<float*>(g.image);
+            net->last_batch = g.batch;
             return SSD_OK;
         }
     if (net->graphs.size() >= 16) net->drop_graphs();
@@ -724,6 +738,8 @@ static int run_graphed(ssd_net* net, std::vector<const void*> key, hipStream_t& 
         net->use_graph = false;
         return SSD_OK;
     }
+    e.image = net->tensors[0].dev;
+    e.batch = net->last_batch;
     net->graphs.push_back(e);
     return SSD_OK;
 }
@@ -1076,6 +1092,11 @@ static int forward_impl(ssd_net* net, const float* image_dev, int B, float* delt
 int ssd_net_forward(ssd_net* net, const float* image_dev, int B, float* deltas_out_dev, float* probs_out_dev,
                     void* stream) {
     SSD_CHECK_ARG(net != nullptr, "ssd_net_forward: net is NULL");
+    if (!net->finalized) {
+        set_error("ssd_net_forward: call ssd_net_finalize() first");
+        return SSD_E_STATE;
+    }
+    SSD_CHECK_ARG(B >= 0 && B <= net->max_batch, "ssd_net_forward: batch %d exceeds max_batch %d", B, net->max_batch);
     hipStream_t st = (hipStream_t)stream;
     return run_graphed(net, {image_dev, deltas_out_dev, probs_out_dev, (const void*)(intptr_t)B, (const void*)1}, st,
                        [&]() { return forward_impl(net, image_dev, B, deltas_out_dev, probs_out_dev, st); });
@@ -1090,14 +1111,28 @@ int ssd_net_predict(ssd_net* net, const float* image_dev, int B, const float* pr
         return SSD_E_STATE;
     }
     const int N = net->num_priors, L = net->L;
-    if (!net->deltas) {
+    SSD_CHECK_ARG(B >= 0 && B <= net->max_batch, "ssd_net_predict: batch %d exceeds max_batch %d", B, net->max_batch);
+    SSD_CHECK_ARG(max_total >= 1, "ssd_net_predict: max_total must be >= 1");
+    // head-output scratch follows max_batch (a re-finalize with a larger batch regrows it); every
+    // reallocation invalidates the captured graphs, which have the old pointers baked in
+    if (net->scratch_batch < net->max_batch) {
+        (void)hipDeviceSynchronize();
+        net->drop_graphs();
+        if (net->deltas) (void)hipFree(net->deltas);
+        if (net->probs) (void)hipFree(net->probs);
+        net->deltas = net->probs = nullptr;
+        net->scratch_batch = 0;
         SSD_HIP(hipMalloc((void**)&net->deltas, (size_t)net->max_batch * N * 4 * sizeof(float)));
         SSD_HIP(hipMalloc((void**)&net->probs, (size_t)net->max_batch * N * L * sizeof(float)));
+        net->scratch_batch = net->max_batch;
     }
     const size_t need = ssd_decode_nms_workspace_bytes(net->max_batch, N, L, max_total);
     if (need > net->nms_ws_bytes) {
+        (void)hipDeviceSynchronize();
+        net->drop_graphs();
         if (net->nms_ws) (void)hipFree(net->nms_ws);
         net->nms_ws = nullptr;
+        net->nms_ws_bytes = 0;
         SSD_HIP(hipMalloc(&net->nms_ws, need));
         net->nms_ws_bytes = need;
     }
@@ -1303,13 +1338,15 @@ int ssd_net_profile_layers(ssd_net* net, const float* image_dev, int B, int reps
     SSD_CHECK_ARG(B >= 1 && B <= net->max_batch, "ssd_net_profile_layers: bad batch %d", B);
     hipStream_t st = (hipStream_t)stream;
     const int N = net->num_priors, L = net->L;
-    float *d = nullptr, *pr = nullptr;
-    SSD_HIP(hipMalloc((void**)&d, (size_t)B * N * 4 * sizeof(float)));
-    SSD_HIP(hipMalloc((void**)&pr, (size_t)B * N * L * sizeof(float)));
+    ScopedDev sd, spr;
+    SSD_HIP(hipMalloc((void**)&sd.p, (size_t)B * N * 4 * sizeof(float)));
+    SSD_HIP(hipMalloc((void**)&spr.p, (size_t)B * N * L * sizeof(float)));
+    float *d = sd.p, *pr = spr.p;
     int rc = forward_impl(net, image_dev, B, d, pr, st);   // warm-up + valid inputs for each layer
-    hipEvent_t e0, e1;
-    (void)hipEventCreate(&e0);
-    (void)hipEventCreate(&e1);
+    ScopedEvent se0, se1;
+    SSD_HIP(hipEventCreate(&se0.e));
+    SSD_HIP(hipEventCreate(&se1.e));
+    hipEvent_t e0 = se0.e, e1 = se1.e;
     for (size_t i = 0; i < net->layers.size() && !rc; ++i) {
         (void)hipEventRecord(e0, st);
         for (int r = 0; r < reps && !rc && layer_runs(*net, net->layers[i]); ++r)
@@ -1320,10 +1357,6 @@ int ssd_net_profile_layers(ssd_net* net, const float* image_dev, int B, int reps
         (void)hipEventElapsedTime(&ms, e0, e1);
         ms_out[i] = ms / reps;
     }
-    (void)hipEventDestroy(e0);
-    (void)hipEventDestroy(e1);
-    (void)hipFree(d);
-    (void)hipFree(pr);
     return rc;
 }
 

@@ -100,16 +100,25 @@ class SSDModel(object):
             cache = os.environ.get("SSD_HIP_TUNE_CACHE")
             path = None
             if cache:
-                path = os.path.join(cache, "%s_%d_%d_b%d.tune" % (self.backbone, self.img_size, self.total_labels, want))
+                # the table is only valid for this library build, this device and this anchor
+                # configuration (head widths follow len(aspect_ratios))
+                ars = "-".join(str(len(a)) for a in self.hyper_params["aspect_ratios"])
+                dev = torch.cuda.get_device_name(torch.cuda.current_device()).replace(" ", "_")
+                ver = lib.ssd_version().decode().replace(" ", "_").replace("/", "_")
+                path = os.path.join(cache, "%s_%d_%d_a%s_b%d_%s_%s.tune" % (
+                    self.backbone, self.img_size, self.total_labels, ars, want, dev, ver))
                 if os.path.exists(path):
                     with open(path, "rb") as f:
                         _h.check(lib.ssd_net_set_tuning(self._net, f.read()), "ssd_net_set_tuning")
             _h.check(lib.ssd_net_finalize(self._net, want), "ssd_net_finalize")
             self._finalized_for = want
             if path and not os.path.exists(path):
+                # one process per GPU may race on the same file: write privately, publish atomically
                 os.makedirs(cache, exist_ok=True)
-                with open(path, "w") as f:
+                tmp = "%s.%d.tmp" % (path, os.getpid())
+                with open(tmp, "w") as f:
                     f.write(self.get_tuning())
+                os.replace(tmp, path)
 
     def __call__(self, images):
         x = _h.to_dev(images)

@@ -82,25 +82,36 @@ def synthetic_weights(model, seed=1, target_frac=0.05):
     _, probs = model(synthetic_images(1, model.img_size, seed=0))
     logp = np.log(np.maximum(probs[0].double().cpu().numpy(), 1e-300))
 
-    def frac(t):
-        lg = logp.copy()
+    def frac(t, g=1.0):
+        lg = logp * g
         lg[:, 0] += t
         e = np.exp(lg - lg.max(-1, keepdims=True))
         p = e / e.sum(-1, keepdims=True)
         return float(((p.argmax(-1) != 0) & (p.max(-1) > 0.5)).mean())
-    lo, hi = -50.0, 50.0
+    # log-probabilities are the logits up to a per-row constant (valid while the softmax is not
+    # saturated, which holds for the un-gained random heads).  If the class spread is too small
+    # for any class to pass 0.5 (VGG16), scale the label kernels and biases by g first: the
+    # logits scale by g exactly.
+    g = 1.0
+    while frac(-1e4, g) < 3 * target_frac and g < 64:
+        g *= 2.0
+    lo, hi = -50.0 * g, 50.0 * g
     for _ in range(40):
         mid = 0.5 * (lo + hi)
-        if frac(mid) > target_frac:
+        if frac(mid, g) > target_frac:
             lo = mid
         else:
             hi = mid
     L = model.total_labels
     upd = {}
     for i in range(1, 7):
-        b = w["%d_conv_label_output/bias" % i].copy()
+        b = w["%d_conv_label_output/bias" % i] * np.float32(g)
         b[0::L] += np.float32(0.5 * (lo + hi))
         w["%d_conv_label_output/bias" % i] = b
         upd["%d_conv_label_output/bias" % i] = b
+        if g != 1.0:
+            k = w["%d_conv_label_output/kernel" % i] * np.float32(g)
+            w["%d_conv_label_output/kernel" % i] = k
+            upd["%d_conv_label_output/kernel" % i] = k
     model.set_weights(upd)
     return w
