@@ -409,11 +409,37 @@ def test_mobilenet_v2_ssd512_forward_parity():
 
 
 def test_weights_container_roundtrip(tmp_path, mbv2):
-    """N3: .npz weights container keyed by Keras variable names."""
+    """N3: weights container.  `*.h5` is a real Keras-layout HDF5 file (pure-Python writer /
+    reader), `*.npz` the NumPy alternative; load_weights sniffs the magic; a Keras file holding a
+    subset of the layers (h5py-written fixture) loads with by_name=True."""
+    import os
     from models.ssd_mobilenet_v2 import get_model
+    from utils import h5_reader
     m, hp, w = mbv2
     path = str(tmp_path / "ssd_mobilenet_v2_model_weights.h5")
     m.save_weights(path)
+    assert h5_reader.is_hdf5(path)
+    npz = str(tmp_path / "w.npz")
+    m.save_weights(npz)
+    m3 = get_model(hp)
+    m3.load_weights(npz)
+    for k, v in m3.get_weights().items():
+        np.testing.assert_array_equal(v, np.asarray(w[k], np.float32))
+    # h5py-written Keras fixture (tests/golden/make_keras_h5.py): partial load by name
+    fx = os.path.join(os.path.dirname(__file__), "golden", "keras_tiny_weights.h5")
+    exp = np.load(os.path.join(os.path.dirname(__file__), "golden", "keras_tiny_expected.npz"))
+    with pytest.raises(ValueError):
+        m3.load_weights(fx)                     # topology mismatch without by_name, like Keras
+    m3.load_weights(fx, by_name=True)
+    got = m3.get_weights()
+    for k in ("Conv1/kernel", "bn_Conv1/gamma", "bn_Conv1/moving_variance", "expanded_conv_depthwise/depthwise_kernel",
+              "expanded_conv_project/kernel"):
+        np.testing.assert_array_equal(got[k], exp[k])
+    np.testing.assert_array_equal(got["block_1_expand/kernel"], np.asarray(w["block_1_expand/kernel"], np.float32))
+    bad = str(tmp_path / "junk.h5")
+    open(bad, "wb").write(b"not a weights file")
+    with pytest.raises(ValueError):
+        m3.load_weights(bad)
     m2 = get_model(hp)
     m2.load_weights(path)
     x = helpers.images(1, 300, seed=5)

@@ -39,6 +39,25 @@ def _max_same_class_iou(boxes, labels):
     return worst
 
 
+def _assert_same_detections(b, l, s, rb, rl, rs, v, what):
+    """Row-for-row equality (labels identical, scores / boxes within the contract's 1e-4 abs);
+    where two scores lie within fp32 noise of each other the two implementations may order the
+    rows differently (the ranks are decided by sub-1e-6 differences of ~50-layer fp32 sums), so
+    on a row mismatch each oracle row must have its own partner among the product's rows with
+    the same label, score and box within 1e-4 and a rank whose score is within 1e-4."""
+    if np.array_equal(l, rl) and np.abs(s - rs).max() <= 1e-4 and np.abs(b - rb).max() <= 1e-4:
+        return
+    used = np.zeros(v, bool)
+    for j in range(v):
+        ok = (~used) & (l[:v] == rl[j]) & (np.abs(s[:v] - rs[j]) <= 1e-4) & (np.abs(b[:v] - rb[j]).max(-1) <= 1e-4)
+        k = np.nonzero(ok)[0]
+        assert k.size > 0, "%s: oracle row %d (label %g score %.6f) has no partner" % (what, j, rl[j], rs[j])
+        k = k[np.argmin(np.abs(k - j))]
+        assert abs(s[k] - rs[min(k, v - 1)]) <= 1e-4 and abs(s[j] - rs[j]) <= 1e-4, "%s: rank %d vs %d" % (what, j, k)
+        used[k] = True
+    assert used.all() and not s[v:].any()
+
+
 def _check_nms_contract(boxes, labels, scores, L, max_total=200, score_thr=0.5):
     B = boxes.shape[0]
     assert boxes.shape == (B, max_total, 4) and labels.shape == (B, max_total) and scores.shape == (B, max_total)
@@ -107,9 +126,7 @@ def test_full_batch_forward_and_decode(backbone, B, S, subset, subset8):
     for j, b in enumerate(sel):
         v = int(tv[j])
         assert int((scores[b] > 0).sum()) == v, "image %d: %d detections vs oracle %d" % (b, (scores[b] > 0).sum(), v)
-        np.testing.assert_array_equal(labels[b], tl[j])
-        assert np.abs(scores[b] - ts[j]).max() <= 1e-4
-        assert np.abs(boxes[b] - tb[j]).max() <= 1e-4
+        _assert_same_detections(boxes[b], labels[b], scores[b], tb[j], tl[j], ts[j], v, "image %d" % b)
     # (b) determinism and batch-composition independence (same tiles: same bits)
     d2, p2 = m(x)
     np.testing.assert_array_equal(_np(d2), d)

@@ -78,15 +78,55 @@ class SSDModel(object):
             out[name] = a
         return out
 
-    def save_weights(self, path):
-        """Weights container: NumPy .npz keyed by Keras variable names (the reference's
-        HDF5 needs h5py, which is not available; utils/io_utils.py:17-29)."""
-        with open(path, "wb") as f:
-            np.savez(f, **self.get_weights())
+    def layer_order(self):
+        """Layer names in parameter-table (= Keras model) order."""
+        out = []
+        for name, _ in self.param_specs:
+            l = name.rsplit("/", 1)[0]
+            if l not in out:
+                out.append(l)
+        return out
 
-    def load_weights(self, path):
-        with np.load(path) as z:
-            self.set_weights({k: z[k] for k in z.files})
+    def save_weights(self, path):
+        """Keras ``Model.save_weights`` (reference trainer.py:65 via ModelCheckpoint,
+        utils/io_utils.py:17-29).  ``*.h5`` / ``*.hdf5`` / ``*.keras``: a real HDF5 file in the
+        Keras layout (utils/h5_writer.py; opens in h5py / Keras ``load_weights``); ``*.npz``: NumPy
+        archive keyed by ``<layer>/<variable>``."""
+        w = self.get_weights()
+        if str(path).endswith(".npz"):
+            with open(path, "wb") as f:
+                np.savez(f, **w)
+            return
+        from utils import h5_writer
+        h5_writer.save_keras_weights(path, w, layer_order=self.layer_order())
+
+    def load_weights(self, path, by_name=False):
+        """Keras ``Model.load_weights`` (reference predictor.py:46, trainer.py:48): the container
+        is recognised by its magic -- HDF5 (a Keras checkpoint, e.g. one trained by the
+        reference; pure-Python reader utils/h5_reader.py) or NumPy ``.npz``.  Without ``by_name``
+        the file must hold exactly this model's variables (Keras raises on a topology mismatch);
+        with ``by_name`` only the layers present in both are loaded."""
+        with open(path, "rb") as f:
+            magic = f.read(8)
+        if magic == b"\x89HDF\r\n\x1a\n":
+            from utils import h5_reader
+            w = h5_reader.load_keras_weights(path)
+        elif magic[:2] == b"PK":
+            with np.load(path) as z:
+                w = {k: z[k] for k in z.files}
+        else:
+            raise ValueError("%s is neither an HDF5 (Keras) nor an .npz weights file" % path)
+        shapes = dict(self.param_specs)
+        if by_name:
+            w = {k: v for k, v in w.items() if k in shapes}
+        else:
+            missing = [k for k in shapes if k not in w]
+            extra = [k for k in w if k not in shapes]
+            if missing or extra:
+                raise ValueError("weights file %s does not match the %s graph: %d missing (e.g. %s), %d unexpected "
+                                 "(e.g. %s); use by_name=True for a partial load" % (
+                                     path, self.backbone, len(missing), missing[:2], len(extra), extra[:2]))
+        self.set_weights(w)
 
     # ------------------------------------------------------------------ execution
     def _ensure(self, B):

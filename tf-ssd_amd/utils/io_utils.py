@@ -17,9 +17,9 @@ def get_log_path(model_type, custom_postfix=""):
 
 def get_model_path(model_type):
     """``trained/ssd_<model_type>_model_weights.h5`` and make sure the directory exists
-    (utils/io_utils.py:17-29).  The container written under that name is a NumPy ``.npz`` keyed
-    by the Keras variable names -- h5py is not available -- but the reference's file name is
-    kept so that scripts and callers see the same path."""
+    (utils/io_utils.py:17-29).  The file is a real HDF5 container in the Keras ``save_weights``
+    layout (utils/h5_writer.py / utils/h5_reader.py: pure Python, h5py is not available), so a
+    checkpoint trained by the reference loads here and vice versa."""
     os.makedirs(_WEIGHTS_DIR, exist_ok=True)
     return os.path.join(_WEIGHTS_DIR, "ssd_%s_model_weights.h5" % model_type)
 
