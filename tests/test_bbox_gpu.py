@@ -222,3 +222,44 @@ def test_encode_decode_roundtrip_gpu(bbox_utils):
     back = _np(bbox_utils.get_deltas_from_bboxes(p, boxes))
     np.testing.assert_allclose(back, d, atol=2e-4)
     np.testing.assert_allclose(back, bo.get_deltas_from_bboxes(p, _np(boxes)), atol=1e-5)
+
+
+def test_eval_update_stats_vs_oracle():
+    """N2: product utils.eval_utils.update_stats (GPU IoU + host bookkeeping) vs the loop-for-loop
+    oracle restatement of reference utils/eval_utils.py:19-54 on synthetic detections: jittered
+    copies of the ground truth (several per box: double matches), wrong labels, background
+    boxes, label-0 zero padding rows, -1-padded ground truth; then the full mAP."""
+    from utils import eval_utils as eu
+    from oracle import eval_oracle as eo
+    rng = np.random.default_rng(17)
+    B, G, T, L = 12, 8, 40, 6
+    gt, gl = helpers.gt_inputs(B, G=G, L=L, seed=5)
+    pb = np.zeros((B, T, 4), np.float32); pl = np.zeros((B, T), np.float32); ps = np.zeros((B, T), np.float32)
+    for b in range(B):
+        g = int((gl[b] > 0).sum())
+        n = int(rng.integers(T // 2, T))
+        for t in range(n):
+            if rng.random() < 0.7:
+                j = int(rng.integers(0, g))
+                pb[b, t] = np.clip(gt[b, j] + rng.normal(0, 0.03, 4), 0, 1)
+                pl[b, t] = gl[b, j] if rng.random() < 0.8 else rng.integers(1, L)
+            else:
+                c = rng.uniform(0.1, 0.9, 2); s = rng.uniform(0.05, 0.3, 2)
+                pb[b, t] = np.clip(np.concatenate([c - s / 2, c + s / 2]), 0, 1)
+                pl[b, t] = rng.integers(1, L)
+            ps[b, t] = rng.uniform(0.5, 1.0)
+        order = np.argsort(-ps[b, :n])
+        pb[b, :n], pl[b, :n], ps[b, :n] = pb[b, order], pl[b, order], ps[b, order]
+    labels = ["bg"] + ["c%d" % i for i in range(1, L)]
+    got = eu.update_stats(pb, pl, ps, gt, gl, eu.init_stats(labels))
+    ref = eo.update_stats(pb, pl, ps, gt, gl, eo.init_stats(labels))
+    for cid in ref:
+        assert got[cid]["total"] == ref[cid]["total"]
+        assert got[cid]["tp"] == ref[cid]["tp"] and got[cid]["fp"] == ref[cid]["fp"], cid
+        np.testing.assert_array_equal(np.asarray(got[cid]["scores"], np.float32), np.asarray(ref[cid]["scores"], np.float32))
+    assert sum(sum(r["tp"]) for r in ref.values()) > 20 and sum(sum(r["fp"]) for r in ref.values()) > 20
+    got, gm = eu.calculate_mAP(got)
+    ref, rm = eo.calculate_mAP(ref)
+    assert float(gm) == float(rm) and 0.05 < float(gm) < 1.0
+    for cid in ref:
+        assert got[cid]["AP"] == ref[cid]["AP"]

@@ -7,7 +7,9 @@ import numpy as np
 from utils import bbox_utils
 
 _IOU_TP = 0.5
-_RECALL_POINTS = np.linspace(0.0, 1.0, 11)
+# the reference's thresholds are np.arange(0, 1.1, 0.1): 0.30000000000000004, 0.6000000000000001,
+# 0.7000000000000001 ... -- a recall of exactly 3/10 does not reach the 4th point (:58)
+_RECALL_POINTS = np.arange(0, 1.1, 0.1)
 
 
 def _host(x):
@@ -66,15 +68,18 @@ def calculate_ap(recall, precision):
 def calculate_mAP(stats):
     """Per class: sort by score, cumulate TP/FP, recall = TP / total, precision = TP / (TP + FP);
     returns ``(stats, mean AP)`` with ``recall``/``precision``/``AP`` added to every record
-    (utils/eval_utils.py:66-85; a class without ground truth divides by zero exactly as there)."""
+    (utils/eval_utils.py:66-85).  Kept as in the reference: the sort is ``np.argsort(-scores)`` on
+    the float32 score array (NumPy's default, unstable sort decides the order of tied scores);
+    a class without ground truth divides by zero (NaN recall -> AP 0) and still enters the mean."""
     per_class = []
     for rec in stats.values():
-        order = np.argsort(-np.asarray(rec["scores"], dtype=np.float64))
-        tp = np.cumsum(np.asarray(rec["tp"])[order]) if order.size else np.zeros(0)
-        fp = np.cumsum(np.asarray(rec["fp"])[order]) if order.size else np.zeros(0)
+        scores = np.array(rec["scores"], dtype=np.float32) if len(rec["scores"]) else np.array(rec["scores"])
+        order = np.argsort(-scores)
+        tp = np.cumsum(np.array(rec["tp"])[order])
+        fp = np.cumsum(np.array(rec["fp"])[order])
         with np.errstate(divide="ignore", invalid="ignore"):
             rec["recall"] = tp / rec["total"]
-            rec["precision"] = tp / (tp + fp)
+            rec["precision"] = tp / (fp + tp)
         rec["AP"] = calculate_ap(rec["recall"], rec["precision"])
         per_class.append(rec["AP"])
     return stats, np.mean(per_class)
