@@ -101,6 +101,28 @@ int ssd_match_encode(const float* priors_dev, const float* gt_boxes_dev,
                      int* label_idx_out_dev, int* match_idx_out_dev, float* onehot_out_dev,
                      void* stream);
 
+/* ---- training loss: ssd_loss.py:8-65 (N1) ----------------------------------------------
+ * CustomLoss.loc_loss_fn + conf_loss_fn in one kernel per image.
+ *   actual_deltas / pred_deltas [B,N,4]; actual_labels (one-hot) / pred_labels (probabilities)
+ *   [B,N,L] (device).  Either pair may be NULL to evaluate only the other term.
+ *   loc_loss [B]  = alpha * sum_pos Huber_{delta=1}(pred - actual summed over 4) / max(#pos, 1),
+ *                   positives = anchors with any non-zero actual delta           (ssd_loss.py:18-33)
+ *   conf_loss [B] = sum_n (pos + neg)_n * CE_n / max(#pos, 1); CE on probabilities renormalised
+ *                   by their sum and clipped to [1e-7, 1-1e-7] ([3P] Keras categorical_crossentropy
+ *                   on a non-Softmax-op tensor); pos = any one-hot column 1.. set; neg = rank of
+ *                   CE*y0 in descending order (ties: lower anchor index) < int(#pos * ratio)
+ *                                                                                  (ssd_loss.py:45-63)
+ * Optional outputs: ce_out [B,N], mask_out [B,N] (pos + neg, the reference's final_mask; 2 where a
+ * positive also ranks as negative), and the gradients of grad_scale * (loc_loss[b] + conf_loss[b])
+ * w.r.t. pred_deltas (grad_deltas [B,N,4]) and w.r.t. the LOGITS behind pred_labels = softmax(z)
+ * (grad_logits [B,N,L]); grad_scale = 1/batch gives the Keras batch-mean objective. */
+size_t ssd_loss_workspace_bytes(int B, int N);
+int ssd_loss(const float* actual_deltas_dev, const float* pred_deltas_dev,
+             const float* actual_labels_dev, const float* pred_labels_dev, int B, int N, int L,
+             float neg_pos_ratio, float loc_loss_alpha, float* loc_loss_dev, float* conf_loss_dev,
+             float* ce_out_dev, float* mask_out_dev, float* grad_deltas_dev, float* grad_logits_dev,
+             float grad_scale, void* workspace_dev, size_t workspace_bytes, void* stream);
+
 /* =====================================================================================
  * Conv family (the TF/Keras ops the models dispatch: SURVEY.md 2.3 K1-K7).
  * All tensors NHWC fp32 on the device.

@@ -32,7 +32,7 @@ LAYERS = [
     ("Conv1_relu", []),
     ("expanded_conv_depthwise", [("expanded_conv_depthwise/depthwise_kernel:0", (3, 3, 32, 1))]),
     ("expanded_conv_project", [("expanded_conv_project/kernel:0", (1, 1, 32, 16))]),
-    ("extra4_1", [("extra4_1/kernel:0", (1, 1, 16, 8)), ("extra4_1/bias:0", (8,))]),   # toy width
+    ("toy_dense", [("toy_dense/kernel:0", (1, 1, 16, 8)), ("toy_dense/bias:0", (8,))]),     # not a layer of the SSD graphs
     ("l2_normalization", [("l2_normalization/Variable:0", (512,))]),   # reference models/ssd_vgg16.py:25-28
     ("scalar_layer", [("scalar_layer/step:0", ())]),
 ]

@@ -21,6 +21,8 @@ compile() {  # src extra-flags
 # box math: separately-rounded fp32 ops (bit-exact indices vs the oracle)
 compile ssd_core.hip
 compile ssd_bbox.hip -ffp-contract=off -fhip-fp32-correctly-rounded-divide-sqrt
+# loss: separately rounded ops too (the hard-negative RANK depends on the per-anchor CE values)
+compile ssd_loss.hip -ffp-contract=off -fhip-fp32-correctly-rounded-divide-sqrt
 for s in ssd_conv.hip ssd_ops.hip ssd_fused.hip ssd_dwproj.hip ssd_net.hip; do
   [ -f "$s" ] && compile "$s"
 done
