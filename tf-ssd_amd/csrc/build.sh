@@ -11,7 +11,7 @@ compile() {  # src extra-flags
   local src=$1; shift
   local obj=build/${src%.*}.o
   if [ "$FORCE" = 1 ] || [ ! -f "$obj" ] || [ "$src" -nt "$obj" ] || [ common.h -nt "$obj" ] \
-     || [ ../../include/ssd_hip.h -nt "$obj" ] || [ ssd_conv.h -nt "$obj" ] || { [ -f "${src%.*}.h" ] && [ "${src%.*}.h" -nt "$obj" ]; }; then
+     || [ ../../include/ssd_hip.h -nt "$obj" ] || [ ssd_conv.h -nt "$obj" ] || [ ssd_net.h -nt "$obj" ] || { [ -f "${src%.*}.h" ] && [ "${src%.*}.h" -nt "$obj" ]; }; then
     echo "hipcc $src"
     $HIPCC $COMMON "$@" -c "$src" -o "$obj"
     need_link=1
@@ -23,7 +23,7 @@ compile ssd_core.hip
 compile ssd_bbox.hip -ffp-contract=off -fhip-fp32-correctly-rounded-divide-sqrt
 # loss: separately rounded ops too (the hard-negative RANK depends on the per-anchor CE values)
 compile ssd_loss.hip -ffp-contract=off -fhip-fp32-correctly-rounded-divide-sqrt
-for s in ssd_conv.hip ssd_ops.hip ssd_fused.hip ssd_dwproj.hip ssd_net.hip; do
+for s in ssd_conv.hip ssd_ops.hip ssd_fused.hip ssd_dwproj.hip ssd_net.hip ssd_train.hip; do
   [ -f "$s" ] && compile "$s"
 done
 if [ $need_link = 1 ] || [ ! -f $OUT ]; then

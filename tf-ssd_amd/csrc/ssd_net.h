@@ -1,0 +1,154 @@
+// Shared definitions of the graph runner (ssd_net.hip) and the training step (ssd_train.hip):
+// parameter table, activation tensors, layer list and the net object behind `ssd_net*`.
+#pragma once
+#include <map>
+#include <string>
+#include <vector>
+
+#include "ssd_conv.h"
+
+struct ssd_train_state;      // csrc/ssd_train.hip
+void ssd_train_state_free(ssd_train_state*);
+
+namespace ssd {
+
+enum LayerKind { LK_CONV = 0, LK_DW, LK_POOL, LK_L2NORM, LK_SOFTMAX, LK_FUSED };
+static const char* kKindName[] = {"conv", "dw", "pool", "l2norm", "softmax", "fused"};
+
+struct Param {
+    std::string name;
+    std::vector<int> shape;
+    size_t count = 0;
+    float* dev = nullptr;
+    bool set = false;
+    bool in_flat = false;     // dev points into the training step's flat parameter buffer (not freed per param)
+};
+
+struct Tensor {
+    std::string name;
+    int H = 0, W = 0, C = 0;
+    size_t per_image = 0;     // floats
+    float* dev = nullptr;     // arena slot, max_batch images
+};
+
+struct Layer {
+    std::string name;
+    LayerKind kind = LK_CONV;
+    int in = -1, out = -1, res = -1;          // tensor ids (out == -1: head conv -> net outputs)
+    int H = 0, W = 0, Cin = 0, Ho = 0, Wo = 0, Cout = 0;
+    int kh = 1, kw = 1, stride = 1, dil = 1, pt = 0, pl = 0, pb = 0, pr = 0, act = 0;
+    int p_kernel = -1, p_bias = -1, p_bn = -1;  // p_bn: index of gamma (beta, mean, var follow)
+    int p_kernel2 = -1, p_bias2 = -1, Cout1 = 0; // fused head conv: second (boxes) kernel/bias, label width
+    int p_gamma = -1;                           // l2norm scale
+    // head routing (floats): level offset, batch stride, pixel stride for the label part
+    // (head_*) and the box part (head2_*); head_kind 3 = fused label+box head conv of one level
+    int head_kind = 0;
+    long head_off = 0, head_bs = 0, head_ps = 0;
+    long head2_off = 0, head2_bs = 0, head2_ps = 0;
+    // derived at finalize
+    float* packed = nullptr;
+    float* scale = nullptr;
+    float* shift = nullptr;
+    int cfg = -1;
+    int split_k = 1;
+    // fused inverted-residual block: LK_FUSED layer points at its three member layers;
+    // members carry the index of their LK_FUSED layer in `fused_by`
+    int f_expand = -1, f_dw = -1, f_project = -1;
+    int f_type = 0;                 // 0: inverted-residual block, 1: stem (Conv1 -> dw -> project),
+                                    // 2: depthwise + project (the expand conv stays a GEMM of its own)
+    int fused_by = -1;
+    int fused_by2 = -1;             // depthwise / project members: their type-2 LK_FUSED layer
+    float* splitk_part = nullptr;   // this layer's own split-K slab (layers may run concurrently)
+    // LK_FUSED: weight copies with the folded BatchNorm scale multiplied in (per output channel)
+    float *fz_we = nullptr, *fz_wd = nullptr, *fz_wp = nullptr;
+    int side = 0;                   // 1, 2: runs on that side stream (SSD head convs)
+    hipEvent_t ev_ready = nullptr;  // recorded on the main stream when this layer's OUTPUT is complete
+};
+
+}  // namespace ssd
+
+struct ssd_net {
+    int backbone = 0, img_size = 300, levels = 6, L = 21;
+    std::vector<int> n_ars;
+    std::vector<ssd::Param> params;
+    std::map<std::string, int> param_index;
+    std::vector<ssd::Tensor> tensors;
+    std::map<std::string, int> tensor_index;
+    std::vector<ssd::Layer> layers;
+    std::vector<int> fmap;          // feature-map size per level
+    std::vector<long> level_off;    // prior offset per level
+    int num_priors = 0;
+    bool finalized = false;
+    bool fuse_blocks = true;        // run eligible inverted-residual blocks as one fused kernel
+    bool fuse_dwproj = true;        // ... and depthwise + project of the others as one kernel
+    int max_batch = 0;
+    int last_batch = 0;
+    std::vector<float*> owned;      // device allocations to free
+    float* arena = nullptr;
+    float* splitk_ws = nullptr;
+    size_t splitk_floats = 0;
+    // predict() scratch
+    float* deltas = nullptr;
+    float* probs = nullptr;
+    void* nms_ws = nullptr;
+    size_t nms_ws_bytes = 0;
+    int scratch_batch = 0;          // batch capacity deltas/probs were allocated for
+    // optional per-layer hipEvent timing of forward()/predict() (bench.py roofline leg)
+    std::map<std::string, std::pair<std::string, int>> preset;   // layer -> (config name, split_k)
+    // hipGraph replay of a whole forward/predict step, keyed by every pointer baked into it
+    bool use_graph = true;
+    struct GraphEntry {
+        std::vector<const void*> key;
+        hipGraphExec_t exec = nullptr;
+        hipGraph_t graph = nullptr;
+        const float* image = nullptr;   // restored on replay (fetch_activation / profile hooks read them)
+        int batch = 0;
+    };
+    std::vector<GraphEntry> graphs;
+    // graphs cannot be captured on the legacy NULL stream (PyTorch's default stream): such
+    // calls are captured/replayed on this BLOCKING stream, which the NULL stream implicitly
+    // orders with (legacy default-stream semantics), so callers see the same ordering.
+    hipStream_t gstream = nullptr;
+    // the head convs only depend on their feature map: they run on `side` concurrently with the
+    // rest of the backbone / extras (fork after the producer, join before the softmax)
+    bool overlap_heads = true;
+    static constexpr int kSides = 2;
+    hipStream_t side[kSides] = {nullptr, nullptr};
+    hipEvent_t ev_side_done[kSides] = {nullptr, nullptr};
+    float* splitk_layers = nullptr;     // per-layer split-K slabs (post-autotune)
+    bool timing = false;
+    ssd_train_state* train = nullptr;    // training step state (csrc/ssd_train.hip), lazily created
+    std::vector<std::vector<hipEvent_t>> timing_events;   // one vector of (layers + 2) events per forward
+
+    ~ssd_net() {
+        for (auto& p : params)
+            if (p.dev && !p.in_flat) (void)hipFree(p.dev);
+        if (train) ssd_train_state_free(train);
+        for (float* p : owned)
+            if (p) (void)hipFree(p);
+        if (arena) (void)hipFree(arena);
+        if (splitk_ws) (void)hipFree(splitk_ws);
+        if (deltas) (void)hipFree(deltas);
+        if (probs) (void)hipFree(probs);
+        if (nms_ws) (void)hipFree(nms_ws);
+        for (auto& v : timing_events)
+            for (auto e : v) (void)hipEventDestroy(e);
+        drop_graphs();
+        if (gstream) (void)hipStreamDestroy(gstream);
+        for (int k = 0; k < kSides; ++k) {
+            if (side[k]) (void)hipStreamDestroy(side[k]);
+            if (ev_side_done[k]) (void)hipEventDestroy(ev_side_done[k]);
+        }
+        for (auto& l : layers)
+            if (l.ev_ready) (void)hipEventDestroy(l.ev_ready);
+        if (splitk_layers) (void)hipFree(splitk_layers);
+    }
+    void drop_graphs() {
+        for (auto& g : graphs) {
+            if (g.exec) (void)hipGraphExecDestroy(g.exec);
+            if (g.graph) (void)hipGraphDestroy(g.graph);
+        }
+        graphs.clear();
+    }
+};
+
