@@ -265,6 +265,39 @@ int ssd_net_read_timing(ssd_net* net, float* ms_sum_out, int* forwards_out);
 int ssd_net_profile_layers(ssd_net* net, const float* image_dev, int B, int reps,
                            float* ms_out, void* stream);
 
+/* =====================================================================================
+ * Training step: what Keras runs for the reference's
+ * `ssd_model.compile(optimizer=Adam(1e-3), loss=[loc_loss_fn, conf_loss_fn])` +
+ * `ssd_model.fit(...)` (trainer.py:50-76), one call per phase so that the host can all-reduce
+ * the flat gradient vector over RCCL between backward and the optimiser.
+ * MobileNetV2 graph (BASELINE configs[3]); training-mode BatchNorm (batch statistics, moving
+ * averages updated with momentum 0.999 / eps 1e-3 of keras-applications MobileNetV2).
+ * ================================================================================== */
+/* Plan the training buffers for `batch` images per step; moves the trainable parameters into
+ * one flat vector (parameter-table order, Keras layouts; moving_mean / moving_variance are not
+ * trainable).  Keeps the Adam state when re-planned for a larger batch. */
+int ssd_net_train_begin(ssd_net* net, int batch);
+size_t ssd_net_trainable_floats(const ssd_net* net);
+/* Offset of a parameter inside the flat trainable vector (-1: unknown / not trainable). */
+long ssd_net_trainable_offset(const ssd_net* net, const char* name);
+/* Training-mode forward + ssd_loss + backward on one batch (device pointers):
+ * image [B,S,S,3], actual_deltas [B,N,4], actual_labels [B,N,L] (calculate_actual_outputs).
+ * grads_flat [ssd_net_trainable_floats] <- d mean_b(loc_b + conf_b) / d parameter (caller-owned);
+ * loc_loss / conf_loss [B] <- per-image loss terms (nullable). */
+int ssd_net_train_forward_backward(ssd_net* net, const float* image_dev, int B,
+                                   const float* actual_deltas_dev, const float* actual_labels_dev,
+                                   float neg_pos_ratio, float loc_loss_alpha, float* grads_flat_dev,
+                                   float* loc_loss_dev, float* conf_loss_dev, void* stream);
+/* Adam (Keras defaults beta1 0.9, beta2 0.999, eps 1e-7; TF ApplyAdam form) on every trainable
+ * parameter; grads are multiplied by grad_scale first (1/world_size after a SUM all-reduce). */
+int ssd_net_adam_step(ssd_net* net, const float* grads_flat_dev, float lr, float beta1, float beta2,
+                      float eps, float grad_scale, void* stream);
+long ssd_net_train_steps(const ssd_net* net);
+/* Debug / parity hook: copy a buffer of the last training forward/backward (batch B) to the host:
+ * "probs", "deltas", "grad_logits", "grad_deltas", "<tensor>", "grad:<tensor>", "pre:<layer>",
+ * "mean:<layer>", "var:<layer>".  Returns the element count (host_out NULL: query). */
+long ssd_net_train_fetch(ssd_net* net, const char* what, int B, float* host_out, size_t cap);
+
 #ifdef __cplusplus
 }
 #endif

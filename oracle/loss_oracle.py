@@ -90,20 +90,11 @@ def conf_loss_fn(actual_labels, pred_labels, neg_pos_ratio=3.0, return_parts=Fal
     return out
 
 
-def torch_loss_and_grads(actual_deltas, actual_labels, pred_deltas, logits, neg_pos_ratio=3.0,
-                         loc_loss_alpha=1.0):
-    """Gradient oracle: the same graph in torch-CPU fp32 ops with autograd.  The model's softmax
-    ([3P] Keras softmax for ndim > 2: exp(x - max) / sum) is part of the graph, so the returned
-    gradients are w.r.t. pred_deltas and the LOGITS.  Objective: Keras batch mean of
-    loc_loss + conf_loss (compile(loss=[loc, conf]), reduction SUM_OVER_BATCH_SIZE).
-    Returns (loc [B], conf [B], probs, d/d pred_deltas, d/d logits)."""
+def torch_loss(yd, yl, pd, probs, neg_pos_ratio=3.0, loc_loss_alpha=1.0, final_mask=None):
+    """The two per-image loss terms on torch tensors (differentiable in pd / probs).  The
+    hard-negative mask is non-differentiable (argsort) and computed in NumPy from the detached
+    per-anchor losses unless ``final_mask`` [B,N] (pos + neg) is supplied."""
     import torch
-    yd = torch.from_numpy(np.asarray(actual_deltas, F32))
-    yl = torch.from_numpy(np.asarray(actual_labels, F32))
-    pd = torch.from_numpy(np.asarray(pred_deltas, F32)).requires_grad_(True)
-    z = torch.from_numpy(np.asarray(logits, F32)).requires_grad_(True)
-    e = torch.exp(z - z.max(-1, keepdim=True).values)
-    probs = e / e.sum(-1, keepdim=True)
     err = pd - yd
     a = err.abs()
     q = torch.minimum(a, torch.tensor(1.0))
@@ -115,9 +106,35 @@ def torch_loss_and_grads(actual_deltas, actual_labels, pred_deltas, logits, neg_
     ce = -(yl * torch.log(out)).sum(-1)
     cpos = (yl[..., 1:] != 0).any(-1).float()
     ctp = cpos.sum(1)
-    tneg = (ctp * neg_pos_ratio).to(torch.int32)
-    neg = torch.from_numpy(hard_negative_mask(ce.detach().numpy(), yl[..., 0].numpy(), tneg.numpy()))
-    conf = ((cpos + neg) * ce).sum(-1) / torch.where(ctp == 0, torch.ones_like(ctp), ctp)
-    total = (loc + conf).mean()
-    total.backward()
+    if final_mask is None:
+        tneg = (ctp * neg_pos_ratio).to(torch.int32)
+        neg = torch.from_numpy(hard_negative_mask(ce.detach().numpy(), yl[..., 0].numpy(), tneg.numpy()))
+        fm = cpos + neg
+    else:
+        fm = torch.as_tensor(np.asarray(final_mask, F32))
+    conf = (fm * ce).sum(-1) / torch.where(ctp == 0, torch.ones_like(ctp), ctp)
+    return loc, conf
+
+
+def keras_softmax(z):
+    """[3P] Keras ``softmax`` for ndim > 2 (TF 2.0/2.1): exp(x - max) / sum."""
+    import torch
+    e = torch.exp(z - z.max(-1, keepdim=True).values)
+    return e / e.sum(-1, keepdim=True)
+
+
+def torch_loss_and_grads(actual_deltas, actual_labels, pred_deltas, logits, neg_pos_ratio=3.0,
+                         loc_loss_alpha=1.0):
+    """Gradient oracle: the same graph in torch-CPU fp32 ops with autograd.  The model's softmax
+    is part of the graph, so the returned gradients are w.r.t. pred_deltas and the LOGITS.
+    Objective: Keras batch mean of loc_loss + conf_loss (compile(loss=[loc, conf]), reduction
+    SUM_OVER_BATCH_SIZE).  Returns (loc [B], conf [B], probs, d/d pred_deltas, d/d logits)."""
+    import torch
+    yd = torch.from_numpy(np.asarray(actual_deltas, F32))
+    yl = torch.from_numpy(np.asarray(actual_labels, F32))
+    pd = torch.from_numpy(np.asarray(pred_deltas, F32)).requires_grad_(True)
+    z = torch.from_numpy(np.asarray(logits, F32)).requires_grad_(True)
+    probs = keras_softmax(z)
+    loc, conf = torch_loss(yd, yl, pd, probs, neg_pos_ratio, loc_loss_alpha)
+    (loc + conf).mean().backward()
     return (loc.detach().numpy(), conf.detach().numpy(), probs.detach().numpy(), pd.grad.numpy(), z.grad.numpy())

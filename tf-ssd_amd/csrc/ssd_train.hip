@@ -1,0 +1,1048 @@
+// Training step of the SSD graphs (reference trainer.py:50-76):
+// training-mode forward (BatchNorm on batch statistics, moving averages updated with Keras'
+// momentum 0.999), the HIP loss (csrc/ssd_loss.hip), backward of every layer and Adam.
+//
+//   conv backward-data   = the forward MFMA implicit-GEMM kernel (conv_mfma_kernel) on dY with the
+//                          180-degree-rotated, in/out-transposed weights; stride-2 3x3 convs go
+//                          through a zero-inserted dY (they are the four small SSD extras);
+//   conv backward-weights= wgrad_mfma_kernel below: dW[K,N] = im2col(X)^T [K,M] * dY [M,N] on
+//                          v_mfma_f32_16x16x4_f32, M split over the grid, deterministic two-stage sum;
+//   depthwise backward   = gather kernels (HBM-bound);
+//   BatchNorm            = two-pass batch statistics and the usual two-reduction backward, all
+//                          reductions deterministic (fixed chunking, fixed order);
+//   Adam                 = one fused kernel over the flat parameter / moment / gradient buffers.
+// Gradients leave through a caller-owned flat buffer (parameter-table order), which is what the
+// host all-reduces over RCCL between backward and the Adam step.
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+
+#include "ssd_net.h"
+
+using namespace ssd;
+
+extern "C" size_t ssd_loss_workspace_bytes(int B, int N);
+extern "C" int ssd_loss(const float*, const float*, const float*, const float*, int, int, int, float, float, float*,
+                        float*, float*, float*, float*, float*, float, void*, size_t, void*);
+
+namespace ssd {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+constexpr float kBnEps = 1e-3f;          // keras-applications MobileNetV2: BatchNormalization(epsilon=1e-3, momentum=0.999)
+constexpr float kBnMomentum = 0.999f;
+
+// ------------------------------------------------------------------ small elementwise kernels
+__device__ __forceinline__ float bn_z(float y, float mean, float istd, float gamma, float beta) {
+    return (y - mean) * istd * gamma + beta;
+}
+__device__ __forceinline__ float act_fwd(float z, int act) {
+    if (act == SSD_ACT_RELU) return fmaxf(z, 0.f);
+    if (act == SSD_ACT_RELU6) return fminf(fmaxf(z, 0.f), 6.f);
+    return z;
+}
+// TF ReluGrad / Relu6Grad: gradient passes strictly inside the linear range
+__device__ __forceinline__ float act_mask(float z, int act) {
+    if (act == SSD_ACT_RELU) return z > 0.f ? 1.f : 0.f;
+    if (act == SSD_ACT_RELU6) return (z > 0.f && z < 6.f) ? 1.f : 0.f;
+    return 1.f;
+}
+
+// out = act(bn(pre)) (+ residual)
+__global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__ pre, const long M, const int C,
+                                                      const float* __restrict__ mean, const float* __restrict__ istd,
+                                                      const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                      const int act, const float* __restrict__ res,
+                                                      float* __restrict__ out) {
+    const long total = M * C;
+    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+        const int c = (int)(e % C);
+        float v = act_fwd(bn_z(pre[e], mean[c], istd[c], gamma[c], beta[c]), act);
+        if (res) v += res[e];
+        out[e] = v;
+    }
+}
+
+// dy = gamma * istd * (dz - dbeta / M - xhat * dgamma / M),  dz = dout * act'(z)
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restrict__ dout, const float* __restrict__ pre,
+                                                          const long M, const int C, const float* __restrict__ mean,
+                                                          const float* __restrict__ istd, const float* __restrict__ gamma,
+                                                          const float* __restrict__ beta, const int act,
+                                                          const float* __restrict__ dgamma,
+                                                          const float* __restrict__ dbeta, float* __restrict__ dy) {
+    const long total = M * C;
+    const float invM = 1.0f / (float)M;
+    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+        const int c = (int)(e % C);
+        const float xh = (pre[e] - mean[c]) * istd[c];
+        const float z = xh * gamma[c] + beta[c];
+        const float dz = dout[e] * act_mask(z, act);
+        dy[e] = gamma[c] * istd[c] * (dz - dbeta[c] * invM - xh * dgamma[c] * invM);
+    }
+}
+
+// dz = dout * (out > 0)   (bias + ReLU layers)
+__global__ __launch_bounds__(256) void act_bwd_kernel(const float* __restrict__ dout, const float* __restrict__ out,
+                                                     const long total, const int act, float* __restrict__ dz) {
+    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256)
+        dz[e] = dout[e] * act_mask(out[e], act);
+}
+
+// dst (+)= src
+__global__ __launch_bounds__(256) void add_kernel(float* __restrict__ dst, const float* __restrict__ src,
+                                                 const long total, const int accumulate) {
+    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256)
+        dst[e] = accumulate ? dst[e] + src[e] : src[e];
+}
+
+// Keras moving average: var -= (var - value) * (1 - momentum)
+__global__ void moving_update_kernel(float* mm, float* mv, const float* mean, const float* var, const int C,
+                                     const float one_minus_momentum) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c < C) {
+        mm[c] -= (mm[c] - mean[c]) * one_minus_momentum;
+        mv[c] -= (mv[c] - var[c]) * one_minus_momentum;
+    }
+}
+
+// Wt[ky'][kx'][co_off + co][ci] = W[kh-1-ky'][kw-1-kx'][ci][co]   (HWIO -> rotated, transposed HWIO
+// with I = CoPad, O = Ci; rows co >= Co stay zero: the caller memsets Wt)
+__global__ __launch_bounds__(256) void rot_transpose_kernel(const float* __restrict__ w, const int kh, const int kw,
+                                                           const int Ci, const int Co, const int CoPad,
+                                                           const int co_off, float* __restrict__ wt) {
+    const long total = (long)kh * kw * Ci * Co;
+    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+        const int co = (int)(e % Co);
+        long r = e / Co;
+        const int ci = (int)(r % Ci);
+        r /= Ci;
+        const int kx = (int)(r % kw), ky = (int)(r / kw);
+        wt[((long)((kh - 1 - ky) * kw + (kw - 1 - kx)) * CoPad + co_off + co) * Ci + ci] = w[e];
+    }
+}
+
+// dense[b][p][c] (row stride ld) = src[b * bs + off + p * ps + c]   (one head level out of the
+// concatenated [B,N,K] gradient buffer); col0 = first dense column written
+__global__ __launch_bounds__(256) void gather_head_kernel(const float* __restrict__ src, const long bs, const long off,
+                                                         const long ps, const int B, const int P, const int C,
+                                                         float* __restrict__ dense, const int ld, const int col0) {
+    const long total = (long)B * P * C;
+    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+        const int c = (int)(e % C);
+        const long r = e / C;
+        const int p = (int)(r % P), b = (int)(r / P);
+        dense[r * ld + col0 + c] = src[b * bs + off + (long)p * ps + c];
+    }
+}
+
+// z[b][2*oy][2*ox][c] = y[b][oy][ox][c], zero elsewhere (the caller memsets z)
+__global__ __launch_bounds__(256) void dilate2_kernel(const float* __restrict__ y, const int B, const int Ho, const int Wo,
+                                                     const int C, const int Hz, const int Wz, float* __restrict__ z) {
+    const long total = (long)B * Ho * Wo * C;
+    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+        const int c = (int)(e % C);
+        long r = e / C;
+        const int ox = (int)(r % Wo);
+        r /= Wo;
+        const int oy = (int)(r % Ho), b = (int)(r / Ho);
+        z[(((long)b * Hz + 2 * oy) * Wz + 2 * ox) * C + c] = y[e];
+    }
+}
+
+// ------------------------------------------------------------------ column reductions over [M][C]
+// block = 64 columns x 4 row lanes; grid = (ceil(C/64), chunks); partial[chunk][2][C].
+enum { RED_SUM = 0, RED_SQDEV = 1, RED_BN_BWD = 2, RED_ACT_BWD = 3 };
+struct RedParams {
+    const float* a;       // SUM/SQDEV: x;  BN_BWD / ACT_BWD: dout
+    const float* b;       // BN_BWD: pre;   ACT_BWD: out (nullable: no activation)
+    const float *mean, *istd, *gamma, *beta;
+    long M;
+    int C, lda, act;
+    long rows_per_chunk;
+    float* partial;
+};
+template <int OP>
+__global__ __launch_bounds__(256) void col_reduce_kernel(const RedParams p) {
+    __shared__ float sh[2][4][64];
+    const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + cl;
+    const long r0 = (long)blockIdx.y * p.rows_per_chunk;
+    const long r1 = r0 + p.rows_per_chunk < p.M ? r0 + p.rows_per_chunk : p.M;
+    float s1 = 0.f, s2 = 0.f;
+    if (c < p.C) {
+        float mean = 0.f, istd = 0.f, gamma = 0.f, beta = 0.f;
+        if (OP == RED_SQDEV || OP == RED_BN_BWD) mean = p.mean[c];
+        if (OP == RED_BN_BWD) { istd = p.istd[c]; gamma = p.gamma[c]; beta = p.beta[c]; }
+        for (long r = r0 + rl; r < r1; r += 4) {
+            const float a = p.a[r * p.lda + c];
+            if (OP == RED_SUM) s1 += a;
+            else if (OP == RED_SQDEV) { const float d = a - mean; s1 += d * d; }
+            else if (OP == RED_BN_BWD) {
+                const float xh = (p.b[r * p.C + c] - mean) * istd;
+                const float dz = a * act_mask(xh * gamma + beta, p.act);
+                s1 += dz;
+                s2 += dz * xh;
+            } else {
+                s1 += p.b ? a * act_mask(p.b[r * p.C + c], p.act) : a;
+            }
+        }
+    }
+    sh[0][rl][cl] = s1;
+    sh[1][rl][cl] = s2;
+    __syncthreads();
+    if (rl == 0 && c < p.C) {
+        const long o = (long)blockIdx.y * 2 * p.C;
+        p.partial[o + c] = (sh[0][0][cl] + sh[0][1][cl]) + (sh[0][2][cl] + sh[0][3][cl]);
+        p.partial[o + p.C + c] = (sh[1][0][cl] + sh[1][1][cl]) + (sh[1][2][cl] + sh[1][3][cl]);
+    }
+}
+// out1[c] = scale * sum_chunks partial[.][0][c]; out2 likewise (nullable); mode 1: out2 = rsqrt(out1 + eps)
+__global__ void col_finalize_kernel(const float* __restrict__ partial, const int chunks, const int C, const float scale,
+                                    float* out1, float* out2, const int mode, const float eps) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    float s1 = 0.f, s2 = 0.f;
+    for (int k = 0; k < chunks; ++k) {
+        s1 += partial[(long)k * 2 * C + c];
+        s2 += partial[(long)k * 2 * C + C + c];
+    }
+    s1 *= scale;
+    s2 *= scale;
+    if (out1) out1[c] = s1;
+    if (mode == 1) out2[c] = 1.0f / sqrtf(s1 + eps);
+    else if (out2) out2[c] = s2;
+}
+// out[i] = sum_chunks partial[chunk][i]
+__global__ __launch_bounds__(256) void chunk_sum_kernel(const float* __restrict__ partial, const int chunks,
+                                                       const long n, float* __restrict__ out) {
+    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < n; e += (long)gridDim.x * 256) {
+        float s = 0.f;
+        for (int k = 0; k < chunks; ++k) s += partial[(long)k * n + e];
+        out[e] = s;
+    }
+}
+
+// ------------------------------------------------------------------ conv backward-weights (MFMA)
+// dW[k = (tap, ci)][n] = sum_m X[pixel(m, tap)][ci] * G[m][n].  One workgroup = a 64 (ci) x 64 (n)
+// tile of one tap over one M chunk; both operands are staged row-major ([m][channel], exactly as
+// they lie in HBM: coalesced 16-byte loads) into LDS with an 80-float row stride, so that the
+// MFMA fragments -- A[i][kk] = X[m0+kk][c0+i], B[kk][j] = G[m0+kk][n0+j], kk = lane/16 -- are
+// conflict-free ds_read_b32 (bank = 16*kk + lane%16).  4 waves = 2 x 2 wave tiles of 32 x 32.
+constexpr int WG_BM = 32, WG_LD = 80;
+struct WgradParams {
+    const float* x;
+    const float* g;
+    float* partial;       // [chunks][K][N]
+    int B, H, W, Cin, Ho, Wo, kh, kw, stride, dil, pad_t, pad_l;
+    int N, ldg, K;
+    long M, rows_per_chunk;
+    int ctiles, ntiles;   // channel tiles per tap, n tiles
+    int vec_x, vec_g;
+};
+__global__ __launch_bounds__(256) void wgrad_mfma_kernel(const WgradParams p) {
+    __shared__ __attribute__((aligned(16))) float Xs[WG_BM * WG_LD];
+    __shared__ __attribute__((aligned(16))) float Gs[WG_BM * WG_LD];
+    int t = blockIdx.x;
+    const int nt = t % p.ntiles;
+    t /= p.ntiles;
+    const int ct = t % p.ctiles, tap = t / p.ctiles;
+    const int ky = tap / p.kw, kx = tap % p.kw;
+    const int c0 = ct * 64, n0 = nt * 64;
+    const long mBeg = (long)blockIdx.y * p.rows_per_chunk;
+    const long mEnd = mBeg + p.rows_per_chunk < p.M ? mBeg + p.rows_per_chunk : p.M;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int wk = wv >> 1, wn = wv & 1;
+    f32x4 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (long m0 = mBeg; m0 < mEnd; m0 += WG_BM) {
+        __syncthreads();
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            const int idx = tid + it * 256;
+            const int row = idx >> 4, q = (idx & 15) * 4;
+            const long m = m0 + row;
+            f32x4 xv = {0.f, 0.f, 0.f, 0.f}, gv = {0.f, 0.f, 0.f, 0.f};
+            if (m < mEnd) {
+                const int ox = (int)(m % p.Wo);
+                const long r = m / p.Wo;
+                const int oy = (int)(r % p.Ho), b = (int)(r / p.Ho);
+                const int iy = oy * p.stride - p.pad_t + ky * p.dil, ix = ox * p.stride - p.pad_l + kx * p.dil;
+                if ((unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W) {
+                    const float* xp = p.x + (((long)b * p.H + iy) * p.W + ix) * p.Cin + c0 + q;
+                    if (p.vec_x && c0 + q + 3 < p.Cin) xv = *reinterpret_cast<const f32x4*>(xp);
+                    else
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)
+                            if (c0 + q + j < p.Cin) xv[j] = xp[j];
+                }
+                const float* gp = p.g + m * p.ldg + n0 + q;
+                if (p.vec_g && n0 + q + 3 < p.N) gv = *reinterpret_cast<const f32x4*>(gp);
+                else
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        if (n0 + q + j < p.N) gv[j] = gp[j];
+            }
+            *reinterpret_cast<f32x4*>(&Xs[row * WG_LD + q]) = xv;
+            *reinterpret_cast<f32x4*>(&Gs[row * WG_LD + q]) = gv;
+        }
+        __syncthreads();
+        const int kk = lane >> 4, li = lane & 15;
+#pragma unroll
+        for (int s = 0; s < WG_BM / 4; ++s) {
+            const int r = 4 * s + kk;
+            const float a0 = Xs[r * WG_LD + wk * 32 + li], a1 = Xs[r * WG_LD + wk * 32 + 16 + li];
+            const float b0 = Gs[r * WG_LD + wn * 32 + li], b1 = Gs[r * WG_LD + wn * 32 + 16 + li];
+            acc[0][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b1, acc[1][1], 0, 0, 0);
+        }
+    }
+    // lane owns D[i = 4*(lane/16) + r][j = lane%16] of each 16x16 tile
+    float* out = p.partial + (long)blockIdx.y * p.K * p.N;
+    const int li = lane & 15, lr = (lane >> 4) * 4;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int n = n0 + wn * 32 + j * 16 + li;
+            if (n >= p.N) continue;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int ci = c0 + wk * 32 + i * 16 + lr + r;
+                if (ci < p.Cin) out[((long)tap * p.Cin + ci) * p.N + n] = acc[i][j][r];
+            }
+        }
+}
+
+// ------------------------------------------------------------------ depthwise 3x3 backward
+struct DwBwdParams {
+    const float* x;       // [B,H,W,C] forward input
+    const float* g;       // [B,Ho,Wo,C] dY
+    const float* w;       // [9][C]
+    float* dx;            // [B,H,W,C]
+    float* partial;       // [chunks][9][C]
+    int B, H, W, C, Ho, Wo, stride, pad_t, pad_l, accumulate;
+    long M, rows_per_chunk;
+};
+// dW[tap][c] partial sums: block = 64 channels x 4 row lanes, grid (ceil(C/64), chunks)
+__global__ __launch_bounds__(256) void dw_wgrad_kernel(const DwBwdParams p) {
+    __shared__ float sh[9][4][64];
+    const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + cl;
+    const long r0 = (long)blockIdx.y * p.rows_per_chunk;
+    const long r1 = r0 + p.rows_per_chunk < p.M ? r0 + p.rows_per_chunk : p.M;
+    float acc[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) acc[t] = 0.f;
+    if (c < p.C) {
+        for (long m = r0 + rl; m < r1; m += 4) {
+            const int ox = (int)(m % p.Wo);
+            const long r = m / p.Wo;
+            const int oy = (int)(r % p.Ho), b = (int)(r / p.Ho);
+            const float g = p.g[m * p.C + c];
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky) {
+                const int iy = oy * p.stride - p.pad_t + ky;
+                if ((unsigned)iy >= (unsigned)p.H) continue;
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx) {
+                    const int ix = ox * p.stride - p.pad_l + kx;
+                    if ((unsigned)ix >= (unsigned)p.W) continue;
+                    acc[ky * 3 + kx] += p.x[(((long)b * p.H + iy) * p.W + ix) * p.C + c] * g;
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < 9; ++t) sh[t][rl][cl] = acc[t];
+    __syncthreads();
+    if (rl == 0 && c < p.C) {
+        float* out = p.partial + (long)blockIdx.y * 9 * p.C;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) out[t * p.C + c] = (sh[t][0][cl] + sh[t][1][cl]) + (sh[t][2][cl] + sh[t][3][cl]);
+    }
+}
+// dX[b][iy][ix][c] = sum_taps dY[b][(iy + pt - ky)/s][(ix + pl - kx)/s][c] * w[ky][kx][c]
+__global__ __launch_bounds__(256) void dw_dgrad_kernel(const DwBwdParams p) {
+    const int C4 = p.C >> 2;
+    const long total = (long)p.B * p.H * p.W * C4;
+    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+        const int c = (int)(e % C4) * 4;
+        long r = e / C4;
+        const int ix = (int)(r % p.W);
+        r /= p.W;
+        const int iy = (int)(r % p.H), b = (int)(r / p.H);
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) {
+            const int ty = iy + p.pad_t - ky;
+            if (ty < 0 || ty % p.stride) continue;
+            const int oy = ty / p.stride;
+            if (oy >= p.Ho) continue;
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+                const int tx = ix + p.pad_l - kx;
+                if (tx < 0 || tx % p.stride) continue;
+                const int ox = tx / p.stride;
+                if (ox >= p.Wo) continue;
+                const f32x4 g = *reinterpret_cast<const f32x4*>(p.g + (((long)b * p.Ho + oy) * p.Wo + ox) * p.C + c);
+                const f32x4 w = *reinterpret_cast<const f32x4*>(p.w + (ky * 3 + kx) * p.C + c);
+                acc += g * w;
+            }
+        }
+        f32x4* d = reinterpret_cast<f32x4*>(p.dx + (((long)b * p.H + iy) * p.W + ix) * p.C + c);
+        *d = p.accumulate ? *d + acc : acc;
+    }
+}
+
+// ------------------------------------------------------------------ Adam (TF training_ops.ApplyAdam form)
+// m += (g - m)(1 - b1); v += (g^2 - v)(1 - b2); var -= alpha * m / (sqrt(v) + eps),
+// alpha = lr * sqrt(1 - b2^t) / (1 - b1^t); g = grad * grad_scale (+ l2 * var where l2mask set)
+__global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ var, float* __restrict__ m, float* __restrict__ v,
+                                                  const float* __restrict__ grad, const long n, const float alpha,
+                                                  const float b1, const float b2, const float eps,
+                                                  const float grad_scale) {
+    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < n; e += (long)gridDim.x * 256) {
+        const float g = grad[e] * grad_scale;
+        const float mm = m[e] + (g - m[e]) * (1.0f - b1);
+        const float vv = v[e] + (g * g - v[e]) * (1.0f - b2);
+        m[e] = mm;
+        v[e] = vv;
+        var[e] -= alpha * mm / (sqrtf(vv) + eps);
+    }
+}
+
+static inline int grid_for(long total) {
+    const long b = (total + 255) / 256;
+    return (int)(b < 1 ? 1 : (b > 16384 ? 16384 : b));
+}
+
+}  // namespace ssd
+
+// ====================================================================== training state
+struct TrainLayer {
+    float* pre = nullptr;        // BN layers: conv / depthwise output before BatchNorm [M][C]
+    float* mean = nullptr;       // [C] batch statistics of the last forward
+    float* var = nullptr;
+    float* istd = nullptr;
+    float* wfwd = nullptr;       // packed forward weights (dense convs)
+    float* wbwd = nullptr;       // packed backward-data weights (rotated + transposed), nullptr: no dgrad
+    int cpad = 0;                // dY channel count the backward-data conv sees (heads: padded to 32)
+    long g_kernel = -1, g_bias = -1, g_gamma = -1, g_beta = -1, g_kernel2 = -1, g_bias2 = -1;
+    bool active = false;
+};
+
+struct ssd_train_state {
+    int batch = 0;
+    size_t P = 0;
+    float *flat = nullptr, *m = nullptr, *v = nullptr;
+    std::vector<long> poff;             // parameter -> offset in the flat trainable vector (-1: not trainable)
+    std::vector<float*> act;            // training activations per tensor (own arena: no finalize needed)
+    std::vector<float*> gact;           // gradient w.r.t. each activation tensor
+    std::vector<char> gwritten;
+    std::vector<TrainLayer> tl;
+    std::vector<float*> owned;
+    float *scratch_dy = nullptr, *scratch_dz = nullptr, *scratch_w = nullptr, *partial = nullptr;
+    size_t partial_floats = 0;
+    float *dgamma_tmp = nullptr, *dbeta_tmp = nullptr;
+    float *deltas = nullptr, *probs = nullptr, *gdeltas = nullptr, *glogits = nullptr;
+    void* loss_ws = nullptr;
+    size_t loss_ws_bytes = 0;
+    long step = 0;
+};
+
+void ssd_train_state_free(ssd_train_state* s) {
+    if (!s) return;
+    for (float* p : s->owned)
+        if (p) (void)hipFree(p);
+    if (s->loss_ws) (void)hipFree(s->loss_ws);
+    delete s;
+}
+
+namespace ssd {
+
+static int talloc(ssd_train_state& s, size_t floats, float** out) {
+    *out = nullptr;
+    if (!floats) return SSD_OK;
+    SSD_HIP(hipMalloc((void**)out, floats * sizeof(float)));
+    s.owned.push_back(*out);
+    return SSD_OK;
+}
+
+static bool trainable(const std::string& name) {
+    const std::string var = name.substr(name.rfind('/') + 1);
+    return var != "moving_mean" && var != "moving_variance";
+}
+
+// layers the training step executes: the un-fused layer list (fused kernels fold inference BatchNorm)
+static bool train_runs(const Layer& l) { return l.kind == LK_CONV || l.kind == LK_DW; }
+
+static long chunks_for(long M, long unit_blocks, long* rows_per_chunk, long min_rows) {
+    long chunks = (2048 + unit_blocks - 1) / unit_blocks;
+    const long maxc = (M + min_rows - 1) / min_rows;
+    if (chunks > maxc) chunks = maxc;
+    if (chunks < 1) chunks = 1;
+    long rpc = (M + chunks - 1) / chunks;
+    rpc = (rpc + 31) / 32 * 32;
+    *rows_per_chunk = rpc;
+    return (M + rpc - 1) / rpc;
+}
+
+static int ensure_partial(ssd_train_state& s, size_t floats) {
+    if (floats <= s.partial_floats) return SSD_OK;
+    // grow-only; the old slab stays owned until the state is freed (sizes are planned once per batch)
+    float* p = nullptr;
+    int rc = talloc(s, floats, &p);
+    if (rc) return rc;
+    s.partial = p;
+    s.partial_floats = floats;
+    return SSD_OK;
+}
+
+template <int OP>
+static int col_reduce(ssd_train_state& s, RedParams p, long* chunks_out, hipStream_t st) {
+    const int ctiles = (p.C + 63) / 64;
+    long rpc = 0;
+    const long chunks = chunks_for(p.M, ctiles, &rpc, 64);
+    int rc = ensure_partial(s, (size_t)chunks * 2 * p.C);
+    if (rc) return rc;
+    p.rows_per_chunk = rpc;
+    p.partial = s.partial;
+    hipLaunchKernelGGL(col_reduce_kernel<OP>, dim3(ctiles, (unsigned)chunks), dim3(256), 0, st, p);
+    SSD_LAUNCH_CHECK();
+    *chunks_out = chunks;
+    return SSD_OK;
+}
+static int col_finalize(ssd_train_state& s, long chunks, int C, float scale, float* out1, float* out2, int mode,
+                        hipStream_t st) {
+    hipLaunchKernelGGL(col_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, st, s.partial, (int)chunks, C, scale,
+                       out1, out2, mode, kBnEps);
+    SSD_LAUNCH_CHECK();
+    return SSD_OK;
+}
+
+// two-pass batch statistics of pre [M][C] -> mean, var (biased), istd
+static int bn_stats(ssd_train_state& s, TrainLayer& t, long M, int C, hipStream_t st) {
+    RedParams p{};
+    p.a = t.pre; p.M = M; p.C = C; p.lda = C;
+    long chunks = 0;
+    int rc = col_reduce<RED_SUM>(s, p, &chunks, st);
+    if (!rc) rc = col_finalize(s, chunks, C, 1.0f / (float)M, t.mean, nullptr, 0, st);
+    if (rc) return rc;
+    p.mean = t.mean;
+    rc = col_reduce<RED_SQDEV>(s, p, &chunks, st);
+    if (!rc) rc = col_finalize(s, chunks, C, 1.0f / (float)M, t.var, t.istd, 1, st);
+    return rc;
+}
+
+static ConvParams dense_conv_params(int B, int H, int W, int Cin, int Cout, int kh, int kw, int stride, int dil,
+                                    int pt, int pl, int Ho, int Wo) {
+    ConvParams p{};
+    p.B = B; p.H = H; p.W = W; p.Cin = Cin; p.Ho = Ho; p.Wo = Wo; p.Cout = Cout;
+    p.kh = kh; p.kw = kw; p.stride = stride; p.dil = dil; p.pad_t = pt; p.pad_l = pl;
+    p.K = kh * kw * Cin;
+    p.Kpad = conv_kpad(p.K);
+    p.Npad = conv_npad(Cout);
+    p.M = (long)B * Ho * Wo;
+    p.split_k = 1;
+    p.out_pixel_stride = Cout;
+    p.out_batch_stride = (long)Ho * Wo * Cout;
+    return p;
+}
+
+static int launch_conv(ConvParams& p, hipStream_t st) {
+    p.vec_store = (((uintptr_t)p.out & 15) == 0) && (p.out_pixel_stride % 4 == 0) && (p.out_batch_stride % 4 == 0);
+    const int cfg = conv_pick_config(p);
+    SSD_UNSUPPORTED_IF(cfg < 0, "train: no conv kernel for Cin=%d Cout=%d k=%dx%d", p.Cin, p.Cout, p.kh, p.kw);
+    return conv_launch(p, cfg, st);
+}
+
+// dW [K][N] (row-major, = Keras HWIO) = im2col(X)^T * G
+static int wgrad(ssd_train_state& s, const Layer& l, int B, const float* x, const float* g, int ldg, int N, float* dW,
+                 hipStream_t st) {
+    WgradParams p{};
+    p.x = x; p.g = g;
+    p.B = B; p.H = l.H; p.W = l.W; p.Cin = l.Cin; p.Ho = l.Ho; p.Wo = l.Wo;
+    p.kh = l.kh; p.kw = l.kw; p.stride = l.stride; p.dil = l.dil; p.pad_t = l.pt; p.pad_l = l.pl;
+    p.N = N; p.ldg = ldg; p.K = l.kh * l.kw * l.Cin;
+    p.M = (long)B * l.Ho * l.Wo;
+    p.ctiles = (l.Cin + 63) / 64;
+    p.ntiles = (N + 63) / 64;
+    p.vec_x = (l.Cin % 4 == 0) && (((uintptr_t)x & 15) == 0);
+    p.vec_g = (ldg % 4 == 0) && (((uintptr_t)g & 15) == 0);
+    const long tiles = (long)l.kh * l.kw * p.ctiles * p.ntiles;
+    long rpc = 0;
+    long chunks = chunks_for(p.M, tiles, &rpc, 128);
+    // bound the slab: chunks * K * N floats
+    const size_t kn = (size_t)p.K * N;
+    while (chunks > 1 && (size_t)chunks * kn > ((size_t)96 << 20)) {
+        rpc *= 2;
+        chunks = (p.M + rpc - 1) / rpc;
+    }
+    int rc = ensure_partial(s, (size_t)chunks * kn);
+    if (rc) return rc;
+    p.rows_per_chunk = rpc;
+    p.partial = s.partial;
+    hipLaunchKernelGGL(wgrad_mfma_kernel, dim3((unsigned)tiles, (unsigned)chunks), dim3(256), 0, st, p);
+    SSD_LAUNCH_CHECK();
+    hipLaunchKernelGGL(chunk_sum_kernel, dim3(grid_for((long)kn)), dim3(256), 0, st, s.partial, (int)chunks, (long)kn, dW);
+    SSD_LAUNCH_CHECK();
+    return SSD_OK;
+}
+
+}  // namespace ssd
+
+extern "C" {
+
+size_t ssd_net_trainable_floats(const ssd_net* net) {
+    if (!net) return 0;
+    size_t n = 0;
+    for (const auto& p : net->params)
+        if (trainable(p.name)) n += p.count;
+    return n;
+}
+
+long ssd_net_trainable_offset(const ssd_net* net, const char* name) {
+    if (!net || !name) return -1;
+    long off = 0;
+    for (const auto& p : net->params) {
+        if (!trainable(p.name)) continue;
+        if (p.name == name) return off;
+        off += (long)p.count;
+    }
+    return -1;
+}
+
+int ssd_net_train_begin(ssd_net* net, int batch) {
+    SSD_CHECK_ARG(net && batch >= 1, "ssd_net_train_begin: bad arguments");
+    SSD_UNSUPPORTED_IF(net->backbone != SSD_MOBILENET_V2,
+                       "ssd_net_train_begin: the training step is built for the MobileNetV2 graph (BASELINE configs[3]); "
+                       "VGG16 needs max-pool / L2-normalisation backward");
+    for (const auto& p : net->params)
+        if (!p.set) {
+            set_error("ssd_net_train_begin: parameter '%s' was never set", p.name.c_str());
+            return SSD_E_STATE;
+        }
+    if (net->train && net->train->batch >= batch) return SSD_OK;
+    // keep optimiser state across a re-plan for a larger batch
+    ssd_train_state* old = net->train;
+    auto* s = new ssd_train_state();
+    s->batch = batch;
+    int rc = SSD_OK;
+    // ---- flat parameter vector (trainable parameters in table order); params point into it
+    s->P = ssd_net_trainable_floats(net);
+    rc = talloc(*s, s->P, &s->flat);
+    if (!rc) rc = talloc(*s, s->P, &s->m);
+    if (!rc) rc = talloc(*s, s->P, &s->v);
+    if (rc) { ssd_train_state_free(s); return rc; }
+    if (old) {
+        SSD_HIP(hipMemcpy(s->m, old->m, s->P * sizeof(float), hipMemcpyDeviceToDevice));
+        SSD_HIP(hipMemcpy(s->v, old->v, s->P * sizeof(float), hipMemcpyDeviceToDevice));
+        s->step = old->step;
+    } else {
+        SSD_HIP(hipMemset(s->m, 0, s->P * sizeof(float)));
+        SSD_HIP(hipMemset(s->v, 0, s->P * sizeof(float)));
+    }
+    s->poff.assign(net->params.size(), -1);
+    long off = 0;
+    for (size_t i = 0; i < net->params.size(); ++i) {
+        Param& p = net->params[i];
+        if (!trainable(p.name)) continue;
+        s->poff[i] = off;
+        SSD_HIP(hipMemcpy(s->flat + off, p.dev, p.count * sizeof(float), hipMemcpyDeviceToDevice));
+        if (!p.in_flat) (void)hipFree(p.dev);
+        p.dev = s->flat + off;
+        p.in_flat = true;
+        off += (long)p.count;
+    }
+    // ---- activations, activation gradients
+    s->act.assign(net->tensors.size(), nullptr);
+    s->gact.assign(net->tensors.size(), nullptr);
+    s->gwritten.assign(net->tensors.size(), 0);
+    for (size_t i = 1; i < net->tensors.size() && !rc; ++i) {
+        rc = talloc(*s, net->tensors[i].per_image * batch, &s->act[i]);
+        if (!rc) rc = talloc(*s, net->tensors[i].per_image * batch, &s->gact[i]);
+    }
+    // ---- per-layer buffers
+    s->tl.assign(net->layers.size(), TrainLayer());
+    size_t max_out = 0, max_dz = 0, max_w = 0;
+    int maxC = 0;
+    for (size_t i = 0; i < net->layers.size() && !rc; ++i) {
+        const Layer& l = net->layers[i];
+        if (!train_runs(l)) continue;
+        TrainLayer& t = s->tl[i];
+        t.active = true;
+        const size_t mc = (size_t)batch * l.Ho * l.Wo * l.Cout;
+        maxC = std::max(maxC, l.Cout);
+        t.g_kernel = s->poff[l.p_kernel];
+        if (l.p_bias >= 0) t.g_bias = s->poff[l.p_bias];
+        if (l.p_kernel2 >= 0) { t.g_kernel2 = s->poff[l.p_kernel2]; t.g_bias2 = s->poff[l.p_bias2]; }
+        if (l.p_bn >= 0) {
+            t.g_gamma = s->poff[l.p_bn];
+            t.g_beta = s->poff[l.p_bn + 1];
+            rc = talloc(*s, mc, &t.pre);
+            if (!rc) rc = talloc(*s, l.Cout, &t.mean);
+            if (!rc) rc = talloc(*s, l.Cout, &t.var);
+            if (!rc) rc = talloc(*s, l.Cout, &t.istd);
+        }
+        if (l.kind == LK_CONV) {
+            const int K = l.kh * l.kw * l.Cin;
+            if (!rc) rc = talloc(*s, (size_t)conv_kpad(K) * conv_npad(l.Cout), &t.wfwd);
+            t.cpad = l.head_kind ? round_up(l.Cout, 32) : l.Cout;
+            if (l.in != 0) {        // the image needs no gradient
+                const int Kb = l.kh * l.kw * t.cpad;
+                if (!rc) rc = talloc(*s, (size_t)conv_kpad(Kb) * conv_npad(l.Cin), &t.wbwd);
+                max_w = std::max(max_w, (size_t)l.kh * l.kw * t.cpad * l.Cin);
+            }
+            size_t dy = (size_t)batch * l.Ho * l.Wo * t.cpad;
+            max_out = std::max(max_out, dy);
+            if (l.stride == 2 && l.in != 0) {
+                const int Hz = (l.Ho - 1) * 2 + 1, Wz = (l.Wo - 1) * 2 + 1;
+                max_dz = std::max(max_dz, (size_t)batch * Hz * Wz * l.Cout);
+            }
+            SSD_UNSUPPORTED_IF(l.stride > 2 || (l.stride == 2 && l.dil != 1), "train: unsupported conv geometry in %s",
+                               l.name.c_str());
+        } else {
+            max_out = std::max(max_out, mc);
+        }
+    }
+    if (!rc) rc = talloc(*s, max_out, &s->scratch_dy);
+    if (!rc) rc = talloc(*s, max_dz, &s->scratch_dz);
+    if (!rc) rc = talloc(*s, max_w, &s->scratch_w);
+    if (!rc) rc = talloc(*s, maxC, &s->dgamma_tmp);
+    if (!rc) rc = talloc(*s, maxC, &s->dbeta_tmp);
+    const size_t N = net->num_priors;
+    if (!rc) rc = talloc(*s, (size_t)batch * N * 4, &s->deltas);
+    if (!rc) rc = talloc(*s, (size_t)batch * N * net->L, &s->probs);
+    if (!rc) rc = talloc(*s, (size_t)batch * N * 4, &s->gdeltas);
+    if (!rc) rc = talloc(*s, (size_t)batch * N * net->L, &s->glogits);
+    if (!rc) {
+        s->loss_ws_bytes = ssd_loss_workspace_bytes(batch, (int)N);
+        if (hipMalloc(&s->loss_ws, s->loss_ws_bytes) != hipSuccess) {
+            set_error("ssd_net_train_begin: loss workspace allocation failed");
+            rc = SSD_E_HIP;
+        }
+    }
+    if (rc) {
+        // parameters already live in the new flat vector: keep the state so they stay valid
+        net->train = s;
+        if (old) { old->flat = nullptr; }
+        return rc;
+    }
+    if (old) ssd_train_state_free(old);
+    net->train = s;
+    net->finalized = false;          // derived inference weights must be rebuilt from the (moved) parameters
+    net->drop_graphs();
+    return SSD_OK;
+}
+
+// Training-mode forward + loss + backward.  grads_flat_dev [ssd_net_trainable_floats] receives
+// d(mean_b (loc_b + conf_b)) / d(parameter) in parameter-table order (Keras layouts);
+// loc_loss_dev / conf_loss_dev [B] receive the per-image loss terms.
+int ssd_net_train_forward_backward(ssd_net* net, const float* image_dev, int B, const float* actual_deltas_dev,
+                                   const float* actual_labels_dev, float neg_pos_ratio, float loc_loss_alpha,
+                                   float* grads_flat_dev, float* loc_loss_dev, float* conf_loss_dev, void* stream) {
+    SSD_CHECK_ARG(net && image_dev && actual_deltas_dev && actual_labels_dev && grads_flat_dev,
+                  "ssd_net_train_forward_backward: NULL argument");
+    if (!net->train) { set_error("ssd_net_train_forward_backward: call ssd_net_train_begin() first"); return SSD_E_STATE; }
+    ssd_train_state& s = *net->train;
+    SSD_CHECK_ARG(B >= 1 && B <= s.batch, "ssd_net_train_forward_backward: batch %d exceeds the planned %d", B, s.batch);
+    hipStream_t st = (hipStream_t)stream;
+    const int N = net->num_priors, L = net->L;
+    s.act[0] = const_cast<float*>(image_dev);
+    int rc = SSD_OK;
+
+    // ------------------------------------------------------------ forward (training mode)
+    for (size_t i = 0; i < net->layers.size(); ++i) {
+        const Layer& l = net->layers[i];
+        TrainLayer& t = s.tl[i];
+        if (!t.active) continue;
+        const long M = (long)B * l.Ho * l.Wo;
+        const float* x = s.act[l.in];
+        if (l.kind == LK_CONV) {
+            const int K = l.kh * l.kw * l.Cin;
+            // re-pack the (just updated) weights: forward and backward-data forms
+            if (l.p_kernel2 < 0) {
+                rc = launch_pack_weights(net->params[l.p_kernel].dev, K, l.Cout, conv_kpad(K), conv_npad(l.Cout), t.wfwd, st);
+            } else {
+                SSD_HIP(hipMemsetAsync(t.wfwd, 0, (size_t)conv_kpad(K) * conv_npad(l.Cout) * sizeof(float), st));
+                rc = launch_pack_weights(net->params[l.p_kernel].dev, K, l.Cout1, conv_kpad(K), l.Cout1, t.wfwd, st);
+                if (!rc) rc = launch_pack_weights(net->params[l.p_kernel2].dev, K, l.Cout - l.Cout1, conv_kpad(K),
+                                                  l.Cout - l.Cout1, t.wfwd + (size_t)l.Cout1 * conv_kpad(K), st);
+            }
+            if (rc) return rc;
+            if (t.wbwd) {
+                const size_t nw = (size_t)l.kh * l.kw * t.cpad * l.Cin;
+                if (t.cpad != l.Cout) SSD_HIP(hipMemsetAsync(s.scratch_w, 0, nw * sizeof(float), st));
+                hipLaunchKernelGGL(rot_transpose_kernel, dim3(grid_for((long)K * l.Cout)), dim3(256), 0, st,
+                                   net->params[l.p_kernel].dev, l.kh, l.kw, l.Cin, l.p_kernel2 >= 0 ? l.Cout1 : l.Cout,
+                                   t.cpad, 0, s.scratch_w);
+                if (l.p_kernel2 >= 0)
+                    hipLaunchKernelGGL(rot_transpose_kernel, dim3(grid_for((long)K * (l.Cout - l.Cout1))), dim3(256), 0, st,
+                                       net->params[l.p_kernel2].dev, l.kh, l.kw, l.Cin, l.Cout - l.Cout1, t.cpad, l.Cout1,
+                                       s.scratch_w);
+                SSD_LAUNCH_CHECK();
+                const int Kb = l.kh * l.kw * t.cpad;
+                rc = launch_pack_weights(s.scratch_w, Kb, l.Cin, conv_kpad(Kb), conv_npad(l.Cin), t.wbwd, st);
+                if (rc) return rc;
+            }
+            ConvParams p = dense_conv_params(B, l.H, l.W, l.Cin, l.Cout, l.kh, l.kw, l.stride, l.dil, l.pt, l.pl, l.Ho, l.Wo);
+            p.in = x;
+            p.w = t.wfwd;
+            if (l.p_bn >= 0) {
+                p.out = t.pre;
+                p.act = SSD_ACT_NONE;
+            } else {
+                p.shift = l.p_bias2 >= 0 ? nullptr : net->params[l.p_bias].dev;
+                p.act = l.act;
+                if (l.head_kind == 0) {
+                    p.out = s.act[l.out];
+                } else {
+                    // fused label + box head conv: bias vector = [label bias | box bias]
+                    SSD_HIP(hipMemcpyAsync(s.dgamma_tmp, net->params[l.p_bias].dev, (size_t)l.Cout1 * sizeof(float),
+                                           hipMemcpyDeviceToDevice, st));
+                    SSD_HIP(hipMemcpyAsync(s.dgamma_tmp + l.Cout1, net->params[l.p_bias2].dev,
+                                           (size_t)(l.Cout - l.Cout1) * sizeof(float), hipMemcpyDeviceToDevice, st));
+                    p.shift = s.dgamma_tmp;
+                    p.out = s.probs + l.head_off;
+                    p.out_pixel_stride = l.head_ps;
+                    p.out_batch_stride = l.head_bs;
+                    p.n_split = l.Cout1;
+                    p.out2 = s.deltas + l.head2_off;
+                    p.out2_pixel_stride = l.head2_ps;
+                    p.out2_batch_stride = l.head2_bs;
+                    p.vec_store2 = (p.out2_pixel_stride % 4 == 0) && (p.out2_batch_stride % 4 == 0);
+                }
+            }
+            rc = launch_conv(p, st);
+            if (rc) return rc;
+        } else {    // depthwise
+            rc = launch_dwconv3x3(x, B, l.H, l.W, l.Cin, l.stride, l.pt, l.pl, l.Ho, l.Wo, net->params[l.p_kernel].dev,
+                                  nullptr, nullptr, SSD_ACT_NONE, t.pre, st);
+            if (rc) return rc;
+        }
+        if (l.p_bn >= 0) {
+            rc = bn_stats(s, t, M, l.Cout, st);
+            if (rc) return rc;
+            hipLaunchKernelGGL(moving_update_kernel, dim3((l.Cout + 255) / 256), dim3(256), 0, st,
+                               net->params[l.p_bn + 2].dev, net->params[l.p_bn + 3].dev, t.mean, t.var, l.Cout,
+                               1.0f - kBnMomentum);
+            hipLaunchKernelGGL(bn_apply_kernel, dim3(grid_for(M * l.Cout)), dim3(256), 0, st, t.pre, M, l.Cout, t.mean,
+                               t.istd, net->params[l.p_bn].dev, net->params[l.p_bn + 1].dev, l.act,
+                               l.res >= 0 ? s.act[l.res] : nullptr, s.act[l.out]);
+            SSD_LAUNCH_CHECK();
+        }
+    }
+    rc = launch_softmax(s.probs, (long)B * N, L, s.probs, st);
+    if (rc) return rc;
+    rc = ssd_loss(actual_deltas_dev, s.deltas, actual_labels_dev, s.probs, B, N, L, neg_pos_ratio, loc_loss_alpha,
+                  loc_loss_dev, conf_loss_dev, nullptr, nullptr, s.gdeltas, s.glogits, 1.0f / (float)B, s.loss_ws,
+                  s.loss_ws_bytes, stream);
+    if (rc) return rc;
+
+    // ------------------------------------------------------------ backward
+    std::fill(s.gwritten.begin(), s.gwritten.end(), 0);
+    for (int i = (int)net->layers.size() - 1; i >= 0; --i) {
+        const Layer& l = net->layers[i];
+        TrainLayer& t = s.tl[i];
+        if (!t.active) continue;
+        const long M = (long)B * l.Ho * l.Wo;
+        const float* x = s.act[l.in];
+        const float* dY = nullptr;       // gradient w.r.t. the conv / depthwise output, dense [M][ldy]
+        int ldy = l.Cout;
+        if (l.head_kind) {
+            ldy = t.cpad;
+            if (t.cpad != l.Cout) SSD_HIP(hipMemsetAsync(s.scratch_dy, 0, (size_t)M * ldy * sizeof(float), st));
+            hipLaunchKernelGGL(gather_head_kernel, dim3(grid_for(M * l.Cout1)), dim3(256), 0, st, s.glogits, l.head_bs,
+                               l.head_off, l.head_ps, B, l.Ho * l.Wo, l.Cout1, s.scratch_dy, ldy, 0);
+            hipLaunchKernelGGL(gather_head_kernel, dim3(grid_for(M * (l.Cout - l.Cout1))), dim3(256), 0, st, s.gdeltas,
+                               l.head2_bs, l.head2_off, l.head2_ps, B, l.Ho * l.Wo, l.Cout - l.Cout1, s.scratch_dy, ldy,
+                               l.Cout1);
+            SSD_LAUNCH_CHECK();
+            dY = s.scratch_dy;
+            // bias gradients = column sums
+            RedParams rp{};
+            rp.a = dY; rp.M = M; rp.C = l.Cout; rp.lda = ldy;
+            long chunks = 0;
+            rc = col_reduce<RED_SUM>(s, rp, &chunks, st);
+            if (!rc) rc = col_finalize(s, chunks, l.Cout, 1.0f, s.dbeta_tmp, nullptr, 0, st);
+            if (rc) return rc;
+            SSD_HIP(hipMemcpyAsync(grads_flat_dev + t.g_bias, s.dbeta_tmp, (size_t)l.Cout1 * sizeof(float),
+                                   hipMemcpyDeviceToDevice, st));
+            SSD_HIP(hipMemcpyAsync(grads_flat_dev + t.g_bias2, s.dbeta_tmp + l.Cout1,
+                                   (size_t)(l.Cout - l.Cout1) * sizeof(float), hipMemcpyDeviceToDevice, st));
+        } else {
+            const float* dOut = s.gact[l.out];
+            if (!s.gwritten[l.out]) {
+                set_error("train: no gradient reached tensor '%s'", net->tensors[l.out].name.c_str());
+                return SSD_E_STATE;
+            }
+            if (l.res >= 0) {       // out = bn(conv) + res: the residual branch receives dOut as is
+                hipLaunchKernelGGL(add_kernel, dim3(grid_for(M * l.Cout)), dim3(256), 0, st, s.gact[l.res], dOut, M * l.Cout,
+                                   (int)s.gwritten[l.res]);
+                SSD_LAUNCH_CHECK();
+                s.gwritten[l.res] = 1;
+            }
+            if (l.p_bn >= 0) {
+                RedParams rp{};
+                rp.a = dOut; rp.b = t.pre; rp.mean = t.mean; rp.istd = t.istd;
+                rp.gamma = net->params[l.p_bn].dev; rp.beta = net->params[l.p_bn + 1].dev;
+                rp.M = M; rp.C = l.Cout; rp.lda = l.Cout; rp.act = l.act;
+                long chunks = 0;
+                rc = col_reduce<RED_BN_BWD>(s, rp, &chunks, st);
+                // s1 = dbeta, s2 = dgamma
+                if (!rc) rc = col_finalize(s, chunks, l.Cout, 1.0f, grads_flat_dev + t.g_beta, grads_flat_dev + t.g_gamma, 0, st);
+                if (rc) return rc;
+                hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid_for(M * l.Cout)), dim3(256), 0, st, dOut, t.pre, M, l.Cout,
+                                   t.mean, t.istd, net->params[l.p_bn].dev, net->params[l.p_bn + 1].dev, l.act,
+                                   grads_flat_dev + t.g_gamma, grads_flat_dev + t.g_beta, s.scratch_dy);
+                SSD_LAUNCH_CHECK();
+                dY = s.scratch_dy;
+            } else {
+                RedParams rp{};
+                rp.a = dOut; rp.b = l.act ? s.act[l.out] : nullptr;
+                rp.M = M; rp.C = l.Cout; rp.lda = l.Cout; rp.act = l.act;
+                long chunks = 0;
+                rc = col_reduce<RED_ACT_BWD>(s, rp, &chunks, st);
+                if (!rc) rc = col_finalize(s, chunks, l.Cout, 1.0f, grads_flat_dev + t.g_bias, nullptr, 0, st);
+                if (rc) return rc;
+                if (l.act) {
+                    hipLaunchKernelGGL(act_bwd_kernel, dim3(grid_for(M * l.Cout)), dim3(256), 0, st, dOut, s.act[l.out],
+                                       M * l.Cout, l.act, s.scratch_dy);
+                    SSD_LAUNCH_CHECK();
+                    dY = s.scratch_dy;
+                } else {
+                    dY = dOut;
+                }
+            }
+        }
+        if (l.kind == LK_DW) {
+            DwBwdParams dp{};
+            dp.x = x; dp.g = dY; dp.w = net->params[l.p_kernel].dev; dp.dx = s.gact[l.in];
+            dp.B = B; dp.H = l.H; dp.W = l.W; dp.C = l.Cin; dp.Ho = l.Ho; dp.Wo = l.Wo;
+            dp.stride = l.stride; dp.pad_t = l.pt; dp.pad_l = l.pl;
+            dp.M = M;
+            dp.accumulate = s.gwritten[l.in];
+            const int ctiles = (l.Cin + 63) / 64;
+            long rpc = 0;
+            const long chunks = chunks_for(M, ctiles, &rpc, 64);
+            rc = ensure_partial(s, (size_t)chunks * 9 * l.Cin);
+            if (rc) return rc;
+            dp.rows_per_chunk = rpc;
+            dp.partial = s.partial;
+            hipLaunchKernelGGL(dw_wgrad_kernel, dim3(ctiles, (unsigned)chunks), dim3(256), 0, st, dp);
+            hipLaunchKernelGGL(chunk_sum_kernel, dim3(grid_for(9L * l.Cin)), dim3(256), 0, st, s.partial, (int)chunks,
+                               9L * l.Cin, grads_flat_dev + t.g_kernel);
+            hipLaunchKernelGGL(dw_dgrad_kernel, dim3(grid_for((long)B * l.H * l.W * (l.Cin / 4))), dim3(256), 0, st, dp);
+            SSD_LAUNCH_CHECK();
+            s.gwritten[l.in] = 1;
+            continue;
+        }
+        // ---- dense conv: weight gradient(s)
+        if (l.p_kernel2 < 0) {
+            rc = wgrad(s, l, B, x, dY, ldy, l.Cout, grads_flat_dev + t.g_kernel, st);
+        } else {
+            rc = wgrad(s, l, B, x, dY, ldy, l.Cout1, grads_flat_dev + t.g_kernel, st);
+            if (!rc) rc = wgrad(s, l, B, x, dY + l.Cout1, ldy, l.Cout - l.Cout1, grads_flat_dev + t.g_kernel2, st);
+        }
+        if (rc) return rc;
+        // ---- data gradient: conv of dY with the rotated / transposed weights
+        if (!t.wbwd) continue;
+        const int d = l.dil, kh = l.kh, kw = l.kw;
+        const float* gin = dY;
+        int Hg = l.Ho, Wg = l.Wo;
+        if (l.stride == 2) {
+            Hg = (l.Ho - 1) * 2 + 1;
+            Wg = (l.Wo - 1) * 2 + 1;
+            SSD_HIP(hipMemsetAsync(s.scratch_dz, 0, (size_t)B * Hg * Wg * ldy * sizeof(float), st));
+            hipLaunchKernelGGL(dilate2_kernel, dim3(grid_for(M * ldy)), dim3(256), 0, st, dY, B, l.Ho, l.Wo, ldy, Hg, Wg,
+                               s.scratch_dz);
+            SSD_LAUNCH_CHECK();
+            gin = s.scratch_dz;
+        }
+        const int pt = (kh - 1) * d - l.pt, pl = (kw - 1) * d - l.pl;
+        SSD_UNSUPPORTED_IF(pt < 0 || pl < 0, "train: backward-data padding of %s is negative", l.name.c_str());
+        ConvParams p = dense_conv_params(B, Hg, Wg, ldy, l.Cin, kh, kw, 1, d, pt, pl, l.H, l.W);
+        p.in = gin;
+        p.w = t.wbwd;
+        p.out = s.gact[l.in];
+        p.act = SSD_ACT_NONE;
+        p.residual = s.gwritten[l.in] ? s.gact[l.in] : nullptr;      // accumulate in the epilogue
+        rc = launch_conv(p, st);
+        if (rc) return rc;
+        s.gwritten[l.in] = 1;
+    }
+    return SSD_OK;
+}
+
+// One Adam update of every trainable parameter from grads_flat_dev (e.g. after the host's RCCL
+// all-reduce; grad_scale = 1 / world_size turns the reduced SUM into the global-batch mean).
+int ssd_net_adam_step(ssd_net* net, const float* grads_flat_dev, float lr, float beta1, float beta2, float eps,
+                      float grad_scale, void* stream) {
+    SSD_CHECK_ARG(net && grads_flat_dev, "ssd_net_adam_step: NULL argument");
+    if (!net->train) { set_error("ssd_net_adam_step: call ssd_net_train_begin() first"); return SSD_E_STATE; }
+    ssd_train_state& s = *net->train;
+    s.step += 1;
+    const double t = (double)s.step;
+    const float alpha = (float)((double)lr * std::sqrt(1.0 - std::pow((double)beta2, t)) / (1.0 - std::pow((double)beta1, t)));
+    hipLaunchKernelGGL(adam_kernel, dim3(grid_for((long)s.P)), dim3(256), 0, (hipStream_t)stream, s.flat, s.m, s.v,
+                       grads_flat_dev, (long)s.P, alpha, beta1, beta2, eps, grad_scale);
+    SSD_LAUNCH_CHECK();
+    net->finalized = false;
+    net->drop_graphs();
+    return SSD_OK;
+}
+
+long ssd_net_train_steps(const ssd_net* net) { return (net && net->train) ? net->train->step : 0; }
+
+// Debug / parity hook: copy a buffer of the LAST ssd_net_train_forward_backward (at batch B) to the
+// host.  what = "probs" | "deltas" | "grad_logits" | "grad_deltas" | "<tensor name>" (training
+// activation) | "grad:<tensor name>" | "pre:<layer name>" (conv output before BatchNorm) |
+// "mean:<layer>" | "var:<layer>".  Returns the element count (host_out may be NULL to query).
+long ssd_net_train_fetch(ssd_net* net, const char* what, int B, float* host_out, size_t cap) {
+    if (!net || !what || !net->train || B < 1 || B > net->train->batch) {
+        set_error("ssd_net_train_fetch: bad arguments / no training state");
+        return SSD_E_INVALID;
+    }
+    ssd_train_state& s = *net->train;
+    const std::string w(what);
+    const float* src = nullptr;
+    size_t n = 0;
+    const size_t N = net->num_priors;
+    if (w == "probs") { src = s.probs; n = (size_t)B * N * net->L; }
+    else if (w == "deltas") { src = s.deltas; n = (size_t)B * N * 4; }
+    else if (w == "grad_logits") { src = s.glogits; n = (size_t)B * N * net->L; }
+    else if (w == "grad_deltas") { src = s.gdeltas; n = (size_t)B * N * 4; }
+    else if (w.rfind("pre:", 0) == 0 || w.rfind("mean:", 0) == 0 || w.rfind("var:", 0) == 0) {
+        const std::string name = w.substr(w.find(':') + 1);
+        for (size_t i = 0; i < net->layers.size(); ++i)
+            if (net->layers[i].name == name && s.tl[i].active && s.tl[i].pre) {
+                const Layer& l = net->layers[i];
+                if (w[0] == 'p') { src = s.tl[i].pre; n = (size_t)B * l.Ho * l.Wo * l.Cout; }
+                else { src = w[0] == 'm' ? s.tl[i].mean : s.tl[i].var; n = l.Cout; }
+            }
+    } else {
+        const bool grad = w.rfind("grad:", 0) == 0;
+        auto it = net->tensor_index.find(grad ? w.substr(5) : w);
+        if (it != net->tensor_index.end() && it->second > 0) {
+            src = grad ? s.gact[it->second] : s.act[it->second];
+            n = net->tensors[it->second].per_image * (size_t)B;
+        }
+    }
+    if (!src) {
+        set_error("ssd_net_train_fetch: unknown buffer '%s'", what);
+        return SSD_E_INVALID;
+    }
+    if (!host_out) return (long)n;
+    if (cap < n) { set_error("ssd_net_train_fetch: buffer too small"); return SSD_E_INVALID; }
+    if (hipDeviceSynchronize() != hipSuccess || hipMemcpy(host_out, src, n * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess) {
+        set_error("ssd_net_train_fetch: copy failed");
+        return SSD_E_HIP;
+    }
+    return (long)n;
+}
+
+}  // extern "C"

@@ -235,6 +235,97 @@ class SSDModel(object):
         self._last_input = x
         return boxes, labels, scores, valid
 
+    # ------------------------------------------------------------------ training
+    def compile(self, optimizer=None, loss=None, learning_rate=1e-3, beta_1=0.9, beta_2=0.999, epsilon=1e-7,
+                neg_pos_ratio=None, loc_loss_alpha=None):
+        """Keras ``Model.compile(optimizer=Adam(learning_rate=1e-3), loss=[loc, conf])`` (reference
+        trainer.py:52-53).  The optimiser is always Adam (the reference's choice) with the Keras
+        defaults; ``loss`` may be the two bound methods of a ``CustomLoss`` (its ratio / alpha are
+        then used)."""
+        self._adam = dict(lr=float(learning_rate), b1=float(beta_1), b2=float(beta_2), eps=float(epsilon))
+        owner = getattr(loss[0], "__self__", None) if loss else None
+        self._neg_pos_ratio = float(neg_pos_ratio if neg_pos_ratio is not None else
+                                    getattr(owner, "neg_pos_ratio", self.hyper_params.get("neg_pos_ratio", 3)))
+        self._loc_alpha = float(loc_loss_alpha if loc_loss_alpha is not None else
+                                getattr(owner, "loc_loss_alpha", self.hyper_params.get("loc_loss_alpha", 1)))
+
+    def trainable_offsets(self):
+        """name -> (offset, shape) inside the flat gradient / parameter vector."""
+        lib = _h.lib()
+        out = {}
+        for name, shape in self.param_specs:
+            off = lib.ssd_net_trainable_offset(self._net, name.encode())
+            if off >= 0:
+                out[name] = (off, shape)
+        return out
+
+    def forward_backward(self, images, actual_deltas, actual_labels):
+        """Training-mode forward + loss + backward.  Returns (loc_loss [B], conf_loss [B],
+        grads_flat) as device tensors; ``grads_flat`` is what data-parallel ranks all-reduce."""
+        if not hasattr(self, "_adam"):
+            self.compile()
+        if not self._weights_set:
+            raise RuntimeError("model has no weights: call set_weights()/load_weights() first")
+        lib = _h.lib()
+        x = _h.to_dev(images)
+        yd, yl = _h.to_dev(actual_deltas), _h.to_dev(actual_labels)
+        B = x.shape[0]
+        if yd.shape != (B, self.num_priors, 4) or yl.shape != (B, self.num_priors, self.total_labels):
+            raise ValueError("bad target shapes %s / %s" % (tuple(yd.shape), tuple(yl.shape)))
+        if getattr(self, "_train_batch", 0) < B:
+            _h.check(lib.ssd_net_train_begin(self._net, B), "ssd_net_train_begin")
+            self._train_batch = B
+            self._finalized_for = 0
+        P = lib.ssd_net_trainable_floats(self._net)
+        if getattr(self, "_grads", None) is None or self._grads.numel() != P:
+            self._grads = torch.empty((P,), dtype=torch.float32, device=x.device)
+        loc = torch.empty((B,), dtype=torch.float32, device=x.device)
+        conf = torch.empty((B,), dtype=torch.float32, device=x.device)
+        _h.check(lib.ssd_net_train_forward_backward(self._net, _h.ptr(x), B, _h.ptr(yd), _h.ptr(yl),
+                                                    self._neg_pos_ratio, self._loc_alpha, _h.ptr(self._grads),
+                                                    _h.ptr(loc), _h.ptr(conf), _h.stream()), "train_forward_backward")
+        self._last_input = x
+        return loc, conf, self._grads
+
+    def apply_gradients(self, grads_flat, learning_rate=None, grad_scale=1.0):
+        a = self._adam
+        lr = a["lr"] if learning_rate is None else float(learning_rate)
+        _h.check(_h.lib().ssd_net_adam_step(self._net, _h.ptr(grads_flat), lr, a["b1"], a["b2"], a["eps"],
+                                            float(grad_scale), _h.stream()), "ssd_net_adam_step")
+        self._finalized_for = 0          # inference weights (folded BN, packed) are stale now
+
+    def train_on_batch(self, images, targets, learning_rate=None):
+        """Keras ``Model.train_on_batch``: one optimisation step; with torch.distributed
+        initialised, gradients are summed over the ranks (RCCL all-reduce over xGMI) and
+        averaged (batch data-parallel).  Returns (loss, loc_loss, conf_loss) host
+        floats of THIS rank's batch (Keras logs the batch means)."""
+        import parallel
+        loc, conf, g = self.forward_backward(images, targets[0], targets[1])
+        world = parallel.allreduce_gradients(g)
+        self.apply_gradients(g, learning_rate, 1.0 / world)
+        lm, cm = float(loc.mean().item()), float(conf.mean().item())
+        return lm + cm, lm, cm
+
+    def train_fetch(self, what, B):
+        """Buffer of the last training forward/backward (debug / parity tests)."""
+        lib = _h.lib()
+        n = lib.ssd_net_train_fetch(self._net, what.encode(), B, None, 0)
+        if n < 0:
+            raise ValueError(lib.ssd_last_error().decode())
+        a = np.empty((n,), np.float32)
+        if lib.ssd_net_train_fetch(self._net, what.encode(), B, a.ctypes.data_as(_h.c_float_p), a.size) < 0:
+            raise RuntimeError(lib.ssd_last_error().decode())
+        return a
+
+    def evaluate_on_batch(self, images, targets):
+        """Validation loss of one batch (inference-mode forward + the HIP loss)."""
+        from ssd_loss import CustomLoss
+        d, p = self(images)
+        cl = CustomLoss(getattr(self, "_neg_pos_ratio", 3.0), getattr(self, "_loc_alpha", 1.0))
+        lm = float(cl.loc_loss_fn(targets[0], d).mean().item())
+        cm = float(cl.conf_loss_fn(targets[1], p).mean().item())
+        return lm + cm, lm, cm
+
     def set_option(self, name, value):
         _h.check(_h.lib().ssd_net_set_option(self._net, name.encode(), int(value)), "set_option")
 

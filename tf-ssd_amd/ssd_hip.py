@@ -91,6 +91,15 @@ _SIGNATURES = {
     "ssd_net_set_timing": (ctypes.c_int, [vp, ctypes.c_int]),
     "ssd_net_read_timing": (ctypes.c_int, [vp, c_float_p, c_int_p]),
     "ssd_net_profile_layers": (ctypes.c_int, [vp, vp, ctypes.c_int, ctypes.c_int, c_float_p, vp]),
+    "ssd_net_train_begin": (ctypes.c_int, [vp, ctypes.c_int]),
+    "ssd_net_trainable_floats": (ctypes.c_size_t, [vp]),
+    "ssd_net_trainable_offset": (ctypes.c_long, [vp, ctypes.c_char_p]),
+    "ssd_net_train_forward_backward": (ctypes.c_int, [vp, vp, ctypes.c_int, vp, vp, ctypes.c_float, ctypes.c_float,
+                                                      vp, vp, vp, vp]),
+    "ssd_net_adam_step": (ctypes.c_int, [vp, vp, ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_float,
+                                         ctypes.c_float, vp]),
+    "ssd_net_train_steps": (ctypes.c_long, [vp]),
+    "ssd_net_train_fetch": (ctypes.c_long, [vp, ctypes.c_char_p, ctypes.c_int, c_float_p, ctypes.c_size_t]),
 }
 
 _lib = None
