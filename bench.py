@@ -91,6 +91,8 @@ def main():
         else:
             raise SystemExit("--img-size is wired for mobilenet_v2 only")
         hp["feature_map_shapes"] = fm
+    if args.train:
+        return train_bench(args, hp, get_model, rank, world, dist)
     model = get_model(hp, max_batch=B)
     weights = data_utils.synthetic_weights(model, seed=1)
     priors = bbox_utils.generate_prior_boxes(hp["feature_map_shapes"], hp["aspect_ratios"])
@@ -212,6 +214,75 @@ def main():
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(args.backbone, hp, weights, priors.cpu().numpy(), args.cpu_sample)
+    if rank == 0:
+        print(json.dumps(result), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+def train_bench(args, hp, get_model, rank, world, dist):
+    """--train: BASELINE.json configs[3] shape (SSD300-MobileNetV2 training, 32 images per GPU,
+    batch data-parallel with an RCCL all-reduce of the flat gradient) -- in fp32, the reference's
+    arithmetic (the bf16 variant of configs[3] is this build's extension and not built).  One step =
+    GPU target assignment + training-mode forward + loss + backward + all-reduce + Adam."""
+    import torch
+    import ssd_hip
+    import parallel
+    from utils import bbox_utils, data_utils, train_utils
+    from ssd_loss import CustomLoss
+    B = args.batch or 32
+    model = get_model(hp, max_batch=B)
+    cl = CustomLoss(hp["neg_pos_ratio"], hp["loc_loss_alpha"])
+    model.compile(learning_rate=1e-3, loss=[cl.loc_loss_fn, cl.conf_loss_fn])
+    priors = bbox_utils.generate_prior_boxes(hp["feature_map_shapes"], hp["aspect_ratios"])
+    x = ssd_hip.to_dev(data_utils.synthetic_images(B, hp["img_size"], seed=rank))
+    gt, gl = data_utils.synthetic_gt(B, total_labels=hp["total_labels"], seed=3 + rank)
+    gt, gl = ssd_hip.to_dev(gt), ssd_hip.to_dev(gl, torch.int32)
+
+    def step():
+        yd, yl = train_utils.calculate_actual_outputs(priors, gt, gl, hp)
+        loc, conf, g = model.forward_backward(x, yd, yl)
+        w = parallel.allreduce_gradients(g)
+        model.apply_gradients(g, 1e-3, 1.0 / w)
+        return loc, conf
+
+    for _ in range(max(args.warmup, 1)):
+        loc, conf = step()
+    first = float((loc + conf).mean().item())
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loc, conf = step()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    last = float((loc + conf).mean().item())
+    fwd_gflop = 2.026 * B                      # SURVEY.md 8d: conv MACs x 2 per image (forward)
+    step_tflops = 3.0 * fwd_gflop * 1e9 / (elapsed / args.steps) / 1e12      # forward + backward-data + backward-weights
+    result = {
+        "metric": "images/sec SSD300 (MobileNetV2) training step", "value": world * B * args.steps / elapsed,
+        "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic (seeded images + ground truth, Keras-default initial weights)",
+        "config": {"workload": "SSD300 mobilenet_v2 training, batch=%d per GPU, fp32, target assignment + fwd + loss + bwd + "
+                               "grad all-reduce + Adam (BASELINE.json configs[3] shape; fp32 instead of bf16)" % B,
+                   "global_batch": world * B, "parallelism": "batch-DP x%d, RCCL all-reduce of %d fp32 gradients" % (
+                       world, ssd_hip.lib().ssd_net_trainable_floats(model._net)),
+                   "loss_first_step": first, "loss_last_step": last},
+        "roofline": {"bound": "mfma", "kernel": "training step (conv fwd + dgrad via conv_mfma_kernel, wgrad_mfma_kernel)",
+                     "achieved": step_tflops, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                     "frac": step_tflops / PEAK_FP32_MFMA_TFLOPS, "traffic": None,
+                     "algorithmic_gflop_per_step": 3.0 * fwd_gflop},
+    }
     if rank == 0:
         print(json.dumps(result), flush=True)
     if dist is not None:

@@ -17,13 +17,50 @@ from oracle import torch_cpu_graph as tg
 BN_MOMENTUM = 0.999
 
 
+class _MaskedAct(torch.autograd.Function):
+    """clamp(x, lo, hi) whose backward uses an externally supplied pass-mask."""
+    @staticmethod
+    def forward(ctx, x, lo, hi, mask):
+        ctx.save_for_backward(mask)
+        return x.clamp(lo, hi) if hi is not None else x.clamp(min=lo)
+
+    @staticmethod
+    def backward(ctx, g):
+        (mask,) = ctx.saved_tensors
+        return g * mask, None, None, None
+
+
+def mobilenet_v2_act_names():
+    """Names of the ReLU / ReLU6 outputs of the MobileNetV2-SSD graph in call order."""
+    names = ["Conv1_relu", "expanded_conv_depthwise_relu"]
+    for k in range(1, 17):
+        names += ["block_%d_expand_relu" % k, "block_%d_depthwise_relu" % k]
+    names.append("out_relu")
+    for i in range(1, 5):
+        names += ["extra%d_1" % i, "extra%d_2" % i]
+    return names
+
+
 class TrainOps(tg.TorchOps):
     """tg.TorchOps with differentiable training-mode ops; tensors stay tensors."""
     moving = None       # list of (moving_mean tensor, new mean, moving_var tensor, new var)
+    masks = None        # optional FIFO of NHWC pass-masks (one per ReLU / ReLU6 call, in call order)
+
+    @staticmethod
+    def _act(x, lo, hi):
+        if TrainOps.masks is None:
+            return F.relu6(x) if hi is not None else torch.relu(x)       # hardtanh / relu backward == TF
+        m = torch.from_numpy(np.ascontiguousarray(TrainOps.masks.pop(0), dtype=np.float32)).permute(0, 3, 1, 2)
+        assert m.shape == x.shape
+        return _MaskedAct.apply(x, lo, hi, m)
 
     @staticmethod
     def output(x):
-        return x.permute(0, 2, 3, 1) if x.dim() == 4 else x
+        # 4-D taps stay NCHW graph nodes with retained gradients (activation-gradient parity);
+        # the [B,N,K] network outputs pass through
+        if x.dim() == 4:
+            x.retain_grad()
+        return x
 
     @staticmethod
     def batch_norm(x, gamma, beta, mean, var, eps=no.BN_EPS):
@@ -35,7 +72,11 @@ class TrainOps(tg.TorchOps):
 
     @staticmethod
     def relu6(x):
-        return F.relu6(x)           # hardtanh backward: zero at and beyond 0 / 6 (== TF Relu6Grad)
+        return TrainOps._act(x, 0.0, 6.0)
+
+    @staticmethod
+    def relu(x):
+        return TrainOps._act(x, 0.0, None)
 
     @staticmethod
     def softmax(x):
@@ -43,10 +84,14 @@ class TrainOps(tg.TorchOps):
 
 
 def train_step(backbone, hyper_params, P, x, actual_deltas, actual_labels, neg_pos_ratio=3.0, loc_loss_alpha=1.0,
-               final_mask=None, threads=None):
+               final_mask=None, threads=None, act_masks=None):
     """One forward/backward.  P: dict name -> float32 array (Keras layouts).  Returns dict with
     per-image ``loc`` / ``conf``, ``deltas`` / ``probs`` (network outputs), ``grads`` {name: array}
-    for every trainable parameter (d mean_b(loc_b + conf_b)), and ``moving`` {name: new value}."""
+    for every trainable parameter (d mean_b(loc_b + conf_b)), and ``moving`` {name: new value}.
+    ``final_mask`` / ``act_masks`` synchronise the NON-DIFFERENTIABLE selections (hard-negative
+    mask; ReLU / ReLU6 pass-masks, one NHWC array per activation in call order) with another
+    implementation: a single fp32-noise flip of such a mask changes gradients by percents (the loss
+    is only piecewise smooth), which would otherwise drown the comparison of the arithmetic."""
     if threads:
         torch.set_num_threads(threads)
     T = {}
@@ -56,7 +101,11 @@ def train_step(backbone, hyper_params, P, x, actual_deltas, actual_labels, neg_p
             t.requires_grad_(True)
         T[name] = t
     TrainOps.moving = []
-    deltas, probs = no.forward(backbone, hyper_params, T, x, ops=TrainOps)
+    TrainOps.masks = list(act_masks) if act_masks is not None else None
+    acts = {}
+    deltas, probs = no.forward(backbone, hyper_params, T, x, acts, ops=TrainOps)
+    assert not TrainOps.masks, "unused activation masks"
+    TrainOps.masks = None
     yd = torch.from_numpy(np.asarray(actual_deltas, np.float32))
     yl = torch.from_numpy(np.asarray(actual_labels, np.float32))
     loc, conf = lo.torch_loss(yd, yl, deltas, probs, neg_pos_ratio, loc_loss_alpha, final_mask)
@@ -67,8 +116,12 @@ def train_step(backbone, hyper_params, P, x, actual_deltas, actual_labels, neg_p
         moving[ids[id(mm)]] = (mm - (mm - mu) * np.float32(1.0 - BN_MOMENTUM)).numpy()
         moving[ids[id(mv)]] = (mv - (mv - va) * np.float32(1.0 - BN_MOMENTUM)).numpy()
     grads = {n: t.grad.numpy() for n, t in T.items() if t.requires_grad and t.grad is not None}
+    act_grads = {n: t.grad.permute(0, 2, 3, 1).contiguous().numpy() for n, t in acts.items()
+                 if isinstance(t, torch.Tensor) and t.dim() == 4 and t.grad is not None}
+    act_vals = {n: t.detach().permute(0, 2, 3, 1).contiguous().numpy() for n, t in acts.items()
+                if isinstance(t, torch.Tensor) and t.dim() == 4}
     return {"loc": loc.detach().numpy(), "conf": conf.detach().numpy(), "deltas": deltas.detach().numpy(),
-            "probs": probs.detach().numpy(), "grads": grads, "moving": moving}
+            "probs": probs.detach().numpy(), "grads": grads, "moving": moving, "act_grads": act_grads, "acts": act_vals}
 
 
 def adam_step(var, m, v, g, t, lr=1e-3, b1=0.9, b2=0.999, eps=1e-7):

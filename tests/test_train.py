@@ -13,6 +13,8 @@ import pytest
 import helpers
 
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GRAD_TOL = 1e-3
+LR = 2e-5      # Adam's first steps move EVERY weight by ~lr: small enough for a first-order decrease on random weights
 
 
 def test_gradient_buckets_and_adam_oracle():
@@ -72,6 +74,25 @@ def test_two_process_gloo_gradient_allreduce(tmp_path, bucket):
         assert p.returncode == 0 and "DP_OK %d" % r in o, o[-2000:]
 
 
+def _hwc(m, name):
+    n = m.train_fetch(name, 1).size
+    for t in ("Conv1_relu", ):
+        pass
+    # per-image H*W*C of a named activation: recover H, W, C from the graph's tensor table
+    import ssd_hip as h
+    lib = h.lib()
+    shapes = getattr(m, "_act_shapes", None)
+    if shapes is None:
+        from oracle import net_oracle as no
+        acts = {}
+        no.forward(m.backbone, m.hyper_params, {k: np.zeros(s, np.float32) + (1.0 if k.endswith("variance") else 0.0)
+                                                for k, s in m.param_specs},
+                   np.zeros((1, m.img_size, m.img_size, 3), np.float32), acts)
+        shapes = m._act_shapes = {k: v.shape[1:] for k, v in acts.items() if getattr(v, "ndim", 0) == 4}
+    assert int(np.prod(shapes[name])) == n
+    return shapes[name]
+
+
 def _targets(hp, B, seed=3):
     from oracle import bbox_oracle as bo
     priors = bo.generate_prior_boxes(hp["feature_map_shapes"], hp["aspect_ratios"])
@@ -105,7 +126,14 @@ def test_train_step_matches_autograd_oracle():
     cl.conf_loss_fn(yl, probs)
     fm = cl.last_final_mask.cpu().numpy()
     torch.set_num_threads(min(16, torch.get_num_threads()))
-    ref = to.train_step("mobilenet_v2", hp, w, x, yd, yl, 3.0, 1.0, final_mask=fm)
+    # ... and with the device's ReLU / ReLU6 pass-masks (a handful of the ~10^7 activations sit
+    # within fp32 noise of 0 or 6; one flipped mask element moves upstream gradients by percents)
+    masks = []
+    for name in to.mobilenet_v2_act_names():
+        a = m.train_fetch(name, B)
+        masks.append(((a > 0) & ((a < 6) | name.startswith("extra"))).reshape(B, *_hwc(m, name)))
+    ref = to.train_step("mobilenet_v2", hp, w, x, yd, yl, 3.0, 1.0, final_mask=fm, act_masks=masks)
+    free = to.train_step("mobilenet_v2", hp, w, x, yd, yl, 3.0, 1.0)          # un-synchronised oracle
     assert np.abs(probs - ref["probs"]).max() <= 1e-4
     assert np.abs(deltas - ref["deltas"]).max() <= 1e-4 * max(1.0, float(np.abs(ref["deltas"]).max()))
     np.testing.assert_allclose(loc, ref["loc"], rtol=1e-4, atol=1e-6)
@@ -115,40 +143,59 @@ def test_train_step_matches_autograd_oracle():
     assert (own != fm).mean() < 1e-3
     offs = m.trainable_offsets()
     assert set(offs) == set(ref["grads"])
-    worst = (0.0, None)
+    flips = 0
+    for name in to.mobilenet_v2_act_names():
+        ra = free["acts"][name]
+        a = m.train_fetch(name, B).reshape(ra.shape)
+        assert np.abs(a - ra).max() <= 1e-3, name
+        flips += int((((a > 0) != (ra > 0)) | ((a < 6) != (ra < 6))).sum())
+    print("activation pass-mask flips vs the free-running oracle: %d" % flips)
+    for name in ("block_13_expand_relu", "out_relu", "extra1_1", "block_1_out"):
+        rg = ref["act_grads"][name]
+        got = m.train_fetch("grad:" + name, B).reshape(rg.shape)
+        assert np.abs(got - rg).max() <= GRAD_TOL * np.abs(rg).max(), name
+    errs = []
     for name, (off, shape) in offs.items():
         got = g[off:off + int(np.prod(shape))].reshape(shape)
         rg = ref["grads"][name]
-        scale = max(float(np.abs(rg).max()), 1e-6)
-        err = float(np.abs(got - rg).max()) / scale
-        if err > worst[0]:
-            worst = (err, name)
-        assert err <= 1e-3, "%s: gradient off by %.3e of its max (%.3e)" % (name, err, scale)
-    print("worst relative gradient error %.2e (%s)" % worst)
+        # (a *_project_BN/beta feeds a BatchNorm'ed conv: its exact gradient is 0 and both sides hold
+        # ~1e-6 of rounding noise -- hence the absolute floor)
+        scale = max(float(np.abs(rg).max()), 1e-2)
+        errs.append((float(np.abs(got - rg).max()) / scale, name, scale))
+    for e in sorted(errs)[-12:]:
+        print("grad %-42s err %.2e of max(|g|max, 1e-2) = %.3e" % (e[1], e[0], e[2]))
+    worst = max(errs)
+    print("worst relative gradient error %.2e (%s)" % worst[:2])
+    assert worst[0] <= GRAD_TOL, "%s: gradient off by %.3e of its max (%.3e)" % (worst[1], worst[0], worst[2])
+    # free-running oracle (its own masks): same gradients up to the effect of the few flipped masks
+    for name, (off, shape) in offs.items():
+        got = g[off:off + int(np.prod(shape))].reshape(shape)
+        rg = free["grads"][name]
+        assert np.abs(got - rg).max() <= 0.2 * max(float(np.abs(rg).max()), 1e-5), name
     # BatchNorm moving averages after one training forward
     after = m.get_weights()
     for name, val in ref["moving"].items():
         np.testing.assert_allclose(after[name], val, rtol=1e-5, atol=1e-6, err_msg=name)
     # Adam: two steps vs the NumPy ApplyAdam on the device's own gradients
     before = {k: v.copy() for k, v in after.items()}
-    m.apply_gradients(m._grads, learning_rate=1e-3)
+    m.apply_gradients(m._grads, learning_rate=LR)
     step1 = m.get_weights()
     st = {}
     for name, (off, shape) in offs.items():
         gg = g[off:off + int(np.prod(shape))].reshape(shape)
-        var, mm, vv = to.adam_step(before[name], np.zeros(shape, np.float32), np.zeros(shape, np.float32), gg, 1)
+        var, mm, vv = to.adam_step(before[name], np.zeros(shape, np.float32), np.zeros(shape, np.float32), gg, 1, lr=LR)
         st[name] = (mm, vv)
-        np.testing.assert_allclose(step1[name], var, rtol=1e-6, atol=1e-7, err_msg=name)
+        np.testing.assert_allclose(step1[name], var, rtol=1e-6, atol=2e-9, err_msg=name)
     loc2, conf2, g2 = m.forward_backward(x, yd, yl)
     g2 = g2.cpu().numpy().copy()
-    m.apply_gradients(m._grads, learning_rate=1e-3, grad_scale=0.5)
+    m.apply_gradients(m._grads, learning_rate=LR, grad_scale=0.5)
     step2 = m.get_weights()
     for name in ("Conv1/kernel", "block_5_depthwise/depthwise_kernel", "bn_Conv1/gamma", "extra2_2/bias",
                  "1_conv_label_output/kernel", "6_conv_boxes_output/bias"):
         off, shape = offs[name]
         gg = g2[off:off + int(np.prod(shape))].reshape(shape) * np.float32(0.5)
-        var, _, _ = to.adam_step(step1[name], st[name][0], st[name][1], gg, 2)
-        np.testing.assert_allclose(step2[name], var, rtol=1e-6, atol=1e-7, err_msg=name)
+        var, _, _ = to.adam_step(step1[name], st[name][0], st[name][1], gg, 2, lr=LR)
+        np.testing.assert_allclose(step2[name], var, rtol=1e-6, atol=2e-9, err_msg=name)
     # the step reduces the loss on the same batch (sanity of sign / scale)
     assert float((loc2 + conf2).mean()) < float((loc + conf).mean())
     # inference after training re-finalises from the updated parameters
