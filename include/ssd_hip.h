@@ -101,6 +101,14 @@ int ssd_match_encode(const float* priors_dev, const float* gt_boxes_dev,
                      int* label_idx_out_dev, int* match_idx_out_dev, float* onehot_out_dev,
                      void* stream);
 
+/* ---- input pipeline: utils/data_utils.py:22-23 (N4) ---------------------------------------
+ * tf.image.convert_image_dtype(uint8 -> float32, x 1/255) + tf.image.resize(bilinear, TF2
+ * half-pixel centres, no antialias) in one kernel.  image_u8 [B,H,W,C] uint8 (device) ->
+ * out [B,out_h,out_w,C] float32 in [0,1].  Images of different sizes go one call each (B = 1)
+ * into their slot of the batch tensor. */
+int ssd_preprocess(const unsigned char* image_u8_dev, int B, int H, int W, int C, int out_h, int out_w,
+                   float* out_dev, void* stream);
+
 /* ---- training loss: ssd_loss.py:8-65 (N1) ----------------------------------------------
  * CustomLoss.loc_loss_fn + conf_loss_fn in one kernel per image.
  *   actual_deltas / pred_deltas [B,N,4]; actual_labels (one-hot) / pred_labels (probabilities)

@@ -285,3 +285,35 @@ def denormalize_bboxes(bboxes, height, width):
     b = np.asarray(bboxes, F32)
     return np.round(np.stack([b[..., 0] * F32(height), b[..., 1] * F32(width),
                               b[..., 2] * F32(height), b[..., 3] * F32(width)], -1)).astype(F32)
+
+
+# --------------------------------------------------------------------------- N4 (input pipeline)
+def preprocess_image(img_u8, out_h, out_w):
+    """utils/data_utils.py:22-23: ``convert_image_dtype(uint8 -> float32)`` (x * float32(1/255))
+    then ``tf.image.resize`` bilinear ([3P] TF 2.x ResizeBilinear CPU kernel: half-pixel centres,
+    no antialias, all arithmetic float32).  img_u8 [H,W,C] or [B,H,W,C]."""
+    x = np.asarray(img_u8)
+    assert x.dtype == np.uint8
+    batched = x.ndim == 4
+    if not batched:
+        x = x[None]
+    B, H, W, C = x.shape
+    f = x.astype(F32) * F32(1.0 / 255.0)
+
+    def weights(out_size, in_size):
+        scale = F32(in_size) / F32(out_size)
+        src = (np.arange(out_size, dtype=F32) + F32(0.5)) * scale - F32(0.5)
+        fl = np.floor(src)
+        lo = np.maximum(fl.astype(np.int64), 0)
+        hi = np.minimum(np.ceil(src).astype(np.int64), in_size - 1)
+        return lo, hi, (src - fl).astype(F32)
+    y0, y1, ly = weights(out_h, H)
+    x0, x1, lx = weights(out_w, W)
+    lx = lx[None, None, :, None]
+    ly = ly[None, :, None, None]
+    tl, tr = f[:, y0][:, :, x0], f[:, y0][:, :, x1]
+    bl, br = f[:, y1][:, :, x0], f[:, y1][:, :, x1]
+    top = tl + (tr - tl) * lx
+    bot = bl + (br - bl) * lx
+    out = (top + (bot - top) * ly).astype(F32)
+    return out if batched else out[0]

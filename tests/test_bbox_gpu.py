@@ -263,3 +263,22 @@ def test_eval_update_stats_vs_oracle():
     assert float(gm) == float(rm) and 0.05 < float(gm) < 1.0
     for cid in ref:
         assert got[cid]["AP"] == ref[cid]["AP"]
+
+
+@pytest.mark.parametrize("H,W,S", [(375, 500, 300), (500, 333, 300), (300, 300, 300), (120, 97, 512), (1, 1, 8)])
+def test_preprocess_gpu_vs_oracle(H, W, S):
+    """N4: ssd_preprocess (uint8 -> float32 [0,1], bilinear resize, TF2 half-pixel centres) bit-exact
+    against the NumPy restatement, single images (VOC-like sizes) and a batch."""
+    from utils import data_utils
+    rng = np.random.default_rng(H * 1000 + W)
+    img = rng.integers(0, 256, (H, W, 3), dtype=np.uint8)
+    out, gb, gl = data_utils.preprocessing({"image": img, "objects": {"bbox": np.zeros((2, 4), np.float32),
+                                                                       "label": np.array([0, 19]),
+                                                                       "is_difficult": np.array([False, True])}},
+                                           S, S, evaluate=True)
+    np.testing.assert_array_equal(_np(out), bo.preprocess_image(img, S, S))
+    assert gl.tolist() == [1] and gb.shape == (1, 4)
+    batch = rng.integers(0, 256, (3, H, W, 3), dtype=np.uint8)
+    np.testing.assert_array_equal(_np(data_utils.preprocess_batch(batch, S, S)), bo.preprocess_image(batch, S, S))
+    with pytest.raises(ValueError):
+        data_utils.preprocess_batch(batch.astype(np.float32), S, S)

@@ -168,3 +168,18 @@ def test_tf_published_nms_known_answers():
         np.testing.assert_array_equal(b[0, :n], exp_b)
         np.testing.assert_array_equal(s[0, :n], c["scores"][c["idx"], c["cls"]])
         assert not b[0, n:].any() and not s[0, n:].any()       # zero padding rows
+
+
+def test_preprocess_oracle_known_answers():
+    """N4: uint8 -> [0,1] + bilinear resize (half-pixel centres).  Hand-checked cases: identity
+    size, 2x upsampling of a ramp (edge clamping), 2x downsampling = mean of 2x2 blocks."""
+    a = np.arange(12, dtype=np.uint8).reshape(2, 2, 3) * 20
+    np.testing.assert_array_equal(bo.preprocess_image(a, 2, 2), a.astype(np.float32) * np.float32(1 / 255))
+    ramp = np.array([[[0], [100]]], np.uint8)                       # 1 x 2 image
+    up = bo.preprocess_image(ramp, 1, 4)[0, :, 0] * 255
+    np.testing.assert_allclose(up, [0, 25, 75, 100], rtol=1e-5, atol=1e-4)     # src = -0.25, 0.25, 0.75, 1.25
+    img = np.random.default_rng(0).integers(0, 256, (6, 8, 3), dtype=np.uint8)
+    down = bo.preprocess_image(img, 3, 4)
+    ref = img.astype(np.float64).reshape(3, 2, 4, 2, 3).mean((1, 3)) / 255
+    np.testing.assert_allclose(down, ref, atol=1e-6)
+    assert bo.preprocess_image(img[None], 5, 7).shape == (1, 5, 7, 3)

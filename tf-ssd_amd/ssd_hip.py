@@ -46,6 +46,7 @@ _SIGNATURES = {
     "ssd_encode_deltas": (ctypes.c_int, [vp, vp, ctypes.c_int, ctypes.c_int, vp, vp]),
     "ssd_match_encode": (ctypes.c_int, [vp, vp, vp, c_float_p, ctypes.c_float] + [ctypes.c_int] * 4 +
                          [vp, vp, vp, vp, vp]),
+    "ssd_preprocess": (ctypes.c_int, [vp] + [ctypes.c_int] * 6 + [vp, vp]),
     "ssd_loss_workspace_bytes": (ctypes.c_size_t, [ctypes.c_int, ctypes.c_int]),
     "ssd_loss": (ctypes.c_int, [vp, vp, vp, vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_float,
                                 ctypes.c_float, vp, vp, vp, vp, vp, vp, ctypes.c_float, vp, ctypes.c_size_t, vp]),

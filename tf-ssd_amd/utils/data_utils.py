@@ -1,13 +1,56 @@
 """Data side of the drop-in.  The reference's ``utils/data_utils.py`` loads PASCAL VOC via
-tensorflow_datasets and resizes on the host; that input pipeline is OUT OF SCOPE of this
-build (needs tfds + network; the metric uses synthetic batches).  What is
-kept: the VOC label list, the padded-batch conventions (gt boxes padded with 0, labels with
+tensorflow_datasets (not available offline: ``get_dataset`` raises) and converts / resizes every
+image with TF ops; here ``preprocessing`` runs that conversion + bilinear resize as one HIP kernel
+(SURVEY.md 8f N4).  Also kept: the VOC label list, the padded-batch conventions (gt boxes padded with 0, labels with
 -1), and seeded synthetic generators shaped like the reference's batches."""
 import numpy as np
 
 VOC_LABELS = ["aeroplane", "bicycle", "bird", "boat", "bottle", "bus", "car", "cat", "chair", "cow",
               "diningtable", "dog", "horse", "motorbike", "person", "pottedplant", "sheep", "sofa",
               "train", "tvmonitor"]
+
+
+def preprocessing(image_data, final_height, final_width, augmentation_fn=None, evaluate=False):
+    """reference utils/data_utils.py:7-30: uint8 image -> float32 [0,1] resized (bilinear) to
+    ``(final_height, final_width)`` ON THE GPU (``ssd_preprocess``: one kernel, no float copy of
+    the original image), labels shifted by +1 (0 is the background), difficult objects dropped when
+    ``evaluate``.  ``image_data`` is the tfds-style dict ``{"image": uint8 [H,W,3], "objects":
+    {"bbox": [G,4], "label": [G], "is_difficult": [G]}}``.  Returns (img device tensor, gt_boxes,
+    gt_labels)."""
+    import torch
+    import ssd_hip as _h
+    img = image_data["image"]
+    img = img if isinstance(img, torch.Tensor) else torch.as_tensor(np.ascontiguousarray(img))
+    if img.dtype != torch.uint8 or img.dim() != 3:
+        raise ValueError("image must be uint8 [H,W,C], got %s %s" % (img.dtype, tuple(img.shape)))
+    src = img.to(_h.device()).contiguous()
+    H, W, C = src.shape
+    out = torch.empty((int(final_height), int(final_width), C), dtype=torch.float32, device=src.device)
+    _h.check(_h.lib().ssd_preprocess(_h.ptr(src), 1, H, W, C, int(final_height), int(final_width), _h.ptr(out),
+                                     _h.stream()), "preprocessing")
+    gt_boxes = np.asarray(image_data["objects"]["bbox"], np.float32)
+    gt_labels = (np.asarray(image_data["objects"]["label"]) + 1).astype(np.int32)
+    if evaluate:
+        not_diff = np.logical_not(np.asarray(image_data["objects"]["is_difficult"], bool))
+        gt_boxes, gt_labels = gt_boxes[not_diff], gt_labels[not_diff]
+    if augmentation_fn:
+        out, gt_boxes = augmentation_fn(out, gt_boxes)
+    return out, gt_boxes, gt_labels
+
+
+def preprocess_batch(images_u8, final_height, final_width):
+    """A batch of same-sized uint8 images [B,H,W,3] -> float32 [B,final_height,final_width,3] in one launch."""
+    import torch
+    import ssd_hip as _h
+    x = images_u8 if isinstance(images_u8, torch.Tensor) else torch.as_tensor(np.ascontiguousarray(images_u8))
+    if x.dtype != torch.uint8 or x.dim() != 4:
+        raise ValueError("images must be uint8 [B,H,W,C]")
+    x = x.to(_h.device()).contiguous()
+    B, H, W, C = x.shape
+    out = torch.empty((B, int(final_height), int(final_width), C), dtype=torch.float32, device=x.device)
+    _h.check(_h.lib().ssd_preprocess(_h.ptr(x), B, H, W, C, int(final_height), int(final_width), _h.ptr(out),
+                                     _h.stream()), "preprocess_batch")
+    return out
 
 
 def get_labels(info=None):
