@@ -318,15 +318,13 @@ def test_entry_point_scripts(tmp_path, monkeypatch, capsys):
     import importlib
     monkeypatch.chdir(tmp_path)
     monkeypatch.setenv("SSD_SYNTHETIC_ITEMS", "40")
-    monkeypatch.setenv("SSD_TRAINER_STEPS", "2")
     predictor = importlib.import_module("predictor")
     b, l, s = predictor.main(["--backbone", "mobilenet_v2"])
     assert b.shape == (40, 200, 4) and l.shape == (40, 200) and s.shape == (40, 200)
     assert ((l > 0).sum(-1) > 0).all() and b.min() >= 0 and b.max() <= 1
-    trainer = importlib.import_module("trainer")
-    trainer.main(["--backbone", "mobilenet_v2", "-handle-gpu"])
+    # (the trainer entry point has its own test: tests/test_train.py::test_trainer_entry_point_fit)
     out = capsys.readouterr().out
-    assert "loc_loss" in out and "step 1" in out
+    assert "predicted 40 images" in out
 
 
 def test_eval_utils_map():

@@ -156,15 +156,18 @@ struct RedParams {
     const float* b;       // BN_BWD: pre;   ACT_BWD: out (nullable: no activation)
     const float *mean, *istd, *gamma, *beta;
     long M;
-    int C, lda, act;
+    int C, lda, act, cw;
     long rows_per_chunk;
     float* partial;
 };
 template <int OP>
 __global__ __launch_bounds__(256) void col_reduce_kernel(const RedParams p) {
-    __shared__ float sh[2][4][64];
-    const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
-    const int c = blockIdx.x * 64 + cl;
+    // block = CW columns x (256 / CW) row lanes; CW in {16, 32, 64} chosen on the host so that
+    // narrow tensors (C = 16 .. 32) keep every lane busy
+    __shared__ float sh[2][256];
+    const int CW = p.cw, RL = 256 / CW;
+    const int cl = threadIdx.x % CW, rl = threadIdx.x / CW;
+    const int c = blockIdx.x * CW + cl;
     const long r0 = (long)blockIdx.y * p.rows_per_chunk;
     const long r1 = r0 + p.rows_per_chunk < p.M ? r0 + p.rows_per_chunk : p.M;
     float s1 = 0.f, s2 = 0.f;
@@ -172,7 +175,7 @@ __global__ __launch_bounds__(256) void col_reduce_kernel(const RedParams p) {
         float mean = 0.f, istd = 0.f, gamma = 0.f, beta = 0.f;
         if (OP == RED_SQDEV || OP == RED_BN_BWD) mean = p.mean[c];
         if (OP == RED_BN_BWD) { istd = p.istd[c]; gamma = p.gamma[c]; beta = p.beta[c]; }
-        for (long r = r0 + rl; r < r1; r += 4) {
+        for (long r = r0 + rl; r < r1; r += RL) {
             const float a = p.a[r * p.lda + c];
             if (OP == RED_SUM) s1 += a;
             else if (OP == RED_SQDEV) { const float d = a - mean; s1 += d * d; }
@@ -186,24 +189,44 @@ __global__ __launch_bounds__(256) void col_reduce_kernel(const RedParams p) {
             }
         }
     }
-    sh[0][rl][cl] = s1;
-    sh[1][rl][cl] = s2;
+    sh[0][threadIdx.x] = s1;
+    sh[1][threadIdx.x] = s2;
     __syncthreads();
     if (rl == 0 && c < p.C) {
+        float t1 = 0.f, t2 = 0.f;
+        for (int k = 0; k < RL; ++k) {           // fixed order: deterministic
+            t1 += sh[0][k * CW + cl];
+            t2 += sh[1][k * CW + cl];
+        }
         const long o = (long)blockIdx.y * 2 * p.C;
-        p.partial[o + c] = (sh[0][0][cl] + sh[0][1][cl]) + (sh[0][2][cl] + sh[0][3][cl]);
-        p.partial[o + p.C + c] = (sh[1][0][cl] + sh[1][1][cl]) + (sh[1][2][cl] + sh[1][3][cl]);
+        p.partial[o + c] = t1;
+        p.partial[o + p.C + c] = t2;
     }
 }
 // out1[c] = scale * sum_chunks partial[.][0][c]; out2 likewise (nullable); mode 1: out2 = rsqrt(out1 + eps)
-__global__ void col_finalize_kernel(const float* __restrict__ partial, const int chunks, const int C, const float scale,
-                                    float* out1, float* out2, const int mode, const float eps) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
+__global__ __launch_bounds__(256) void col_finalize_kernel(const float* __restrict__ partial, const int chunks, const int C,
+                                                          const float scale, float* out1, float* out2, const int mode,
+                                                          const float eps) {
+    // block = 16 columns x 16 chunk lanes (lane k sums chunks k, k+16, ... in order; the 16 lane
+    // sums are combined in a fixed order: deterministic).  The data is tiny; the kernel is latency
+    // bound, hence many short dependent chains instead of few long ones.
+    __shared__ float sh[2][16][16];
+    const int cl = threadIdx.x & 15, kl = threadIdx.x >> 4;
+    const int c = blockIdx.x * 16 + cl;
     float s1 = 0.f, s2 = 0.f;
-    for (int k = 0; k < chunks; ++k) {
-        s1 += partial[(long)k * 2 * C + c];
-        s2 += partial[(long)k * 2 * C + C + c];
+    if (c < C)
+        for (int k = kl; k < chunks; k += 16) {
+            s1 += partial[(long)k * 2 * C + c];
+            s2 += partial[(long)k * 2 * C + C + c];
+        }
+    sh[0][kl][cl] = s1;
+    sh[1][kl][cl] = s2;
+    __syncthreads();
+    if (kl != 0 || c >= C) return;
+    s1 = s2 = 0.f;
+    for (int k = 0; k < 16; ++k) {
+        s1 += sh[0][k][cl];
+        s2 += sh[1][k][cl];
     }
     s1 *= scale;
     s2 *= scale;
@@ -211,13 +234,21 @@ __global__ void col_finalize_kernel(const float* __restrict__ partial, const int
     if (mode == 1) out2[c] = 1.0f / sqrtf(s1 + eps);
     else if (out2) out2[c] = s2;
 }
-// out[i] = sum_chunks partial[chunk][i]
+// out[i] = sum_chunks partial[chunk][i]: block = 64 elements x 4 chunk lanes (lane k sums chunks
+// k, k+4, ... in order, then the 4 lane sums in a fixed order: deterministic)
 __global__ __launch_bounds__(256) void chunk_sum_kernel(const float* __restrict__ partial, const int chunks,
                                                        const long n, float* __restrict__ out) {
-    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < n; e += (long)gridDim.x * 256) {
+    __shared__ float sh[4][64];
+    const int el = threadIdx.x & 63, kl = threadIdx.x >> 6;
+    for (long e0 = (long)blockIdx.x * 64; e0 < n; e0 += (long)gridDim.x * 64) {
+        const long e = e0 + el;
         float s = 0.f;
-        for (int k = 0; k < chunks; ++k) s += partial[(long)k * n + e];
-        out[e] = s;
+        if (e < n)
+            for (int k = kl; k < chunks; k += 4) s += partial[(long)k * n + e];
+        __syncthreads();
+        sh[kl][el] = s;
+        __syncthreads();
+        if (kl == 0 && e < n) out[e] = (sh[0][el] + sh[1][el]) + (sh[2][el] + sh[3][el]);
     }
 }
 
@@ -327,22 +358,23 @@ struct DwBwdParams {
     int B, H, W, C, Ho, Wo, stride, pad_t, pad_l, accumulate;
     long M, rows_per_chunk;
 };
-// dW[tap][c] partial sums: block = 64 channels x 4 row lanes, grid (ceil(C/64), chunks)
+// dW[tap][c] partial sums: block = 16 channel quads (64 channels, 16-byte loads) x 16 row lanes,
+// grid (ceil(C/64), chunks)
 __global__ __launch_bounds__(256) void dw_wgrad_kernel(const DwBwdParams p) {
-    __shared__ float sh[9][4][64];
-    const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
-    const int c = blockIdx.x * 64 + cl;
+    __shared__ __attribute__((aligned(16))) float sh[16][64];
+    const int ql = threadIdx.x & 15, rl = threadIdx.x >> 4;
+    const int c = blockIdx.x * 64 + ql * 4;
     const long r0 = (long)blockIdx.y * p.rows_per_chunk;
     const long r1 = r0 + p.rows_per_chunk < p.M ? r0 + p.rows_per_chunk : p.M;
-    float acc[9];
+    f32x4 acc[9];
 #pragma unroll
-    for (int t = 0; t < 9; ++t) acc[t] = 0.f;
+    for (int t = 0; t < 9; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
     if (c < p.C) {
-        for (long m = r0 + rl; m < r1; m += 4) {
+        for (long m = r0 + rl; m < r1; m += 16) {
             const int ox = (int)(m % p.Wo);
             const long r = m / p.Wo;
             const int oy = (int)(r % p.Ho), b = (int)(r / p.Ho);
-            const float g = p.g[m * p.C + c];
+            const f32x4 g = *reinterpret_cast<const f32x4*>(p.g + m * p.C + c);
 #pragma unroll
             for (int ky = 0; ky < 3; ++ky) {
                 const int iy = oy * p.stride - p.pad_t + ky;
@@ -351,18 +383,23 @@ __global__ __launch_bounds__(256) void dw_wgrad_kernel(const DwBwdParams p) {
                 for (int kx = 0; kx < 3; ++kx) {
                     const int ix = ox * p.stride - p.pad_l + kx;
                     if ((unsigned)ix >= (unsigned)p.W) continue;
-                    acc[ky * 3 + kx] += p.x[(((long)b * p.H + iy) * p.W + ix) * p.C + c] * g;
+                    acc[ky * 3 + kx] += *reinterpret_cast<const f32x4*>(p.x + (((long)b * p.H + iy) * p.W + ix) * p.C + c) * g;
                 }
             }
         }
     }
+    float* out = p.partial + (long)blockIdx.y * 9 * p.C;
 #pragma unroll
-    for (int t = 0; t < 9; ++t) sh[t][rl][cl] = acc[t];
-    __syncthreads();
-    if (rl == 0 && c < p.C) {
-        float* out = p.partial + (long)blockIdx.y * 9 * p.C;
+    for (int t = 0; t < 9; ++t) {
+        __syncthreads();
+        *reinterpret_cast<f32x4*>(&sh[rl][ql * 4]) = acc[t];
+        __syncthreads();
+        if (threadIdx.x < 64 && blockIdx.x * 64 + (int)threadIdx.x < p.C) {
+            float v = 0.f;
 #pragma unroll
-        for (int t = 0; t < 9; ++t) out[t * p.C + c] = (sh[t][0][cl] + sh[t][1][cl]) + (sh[t][2][cl] + sh[t][3][cl]);
+            for (int k = 0; k < 16; ++k) v += sh[k][threadIdx.x];       // fixed order: deterministic
+            out[t * p.C + blockIdx.x * 64 + threadIdx.x] = v;
+        }
     }
 }
 // dX[b][iy][ix][c] = sum_taps dY[b][(iy + pt - ky)/s][(ix + pl - kx)/s][c] * w[ky][kx][c]
@@ -480,10 +517,11 @@ static bool trainable(const std::string& name) {
 // layers the training step executes: the un-fused layer list (fused kernels fold inference BatchNorm)
 static bool train_runs(const Layer& l) { return l.kind == LK_CONV || l.kind == LK_DW; }
 
-static long chunks_for(long M, long unit_blocks, long* rows_per_chunk, long min_rows) {
-    long chunks = (2048 + unit_blocks - 1) / unit_blocks;
+static long chunks_for(long M, long unit_blocks, long* rows_per_chunk, long min_rows, long max_chunks) {
+    long chunks = (2048 + unit_blocks - 1) / unit_blocks;          // ~8 workgroups per CU in total
     const long maxc = (M + min_rows - 1) / min_rows;
     if (chunks > maxc) chunks = maxc;
+    if (chunks > max_chunks) chunks = max_chunks;                    // second-stage sums walk the chunks serially
     if (chunks < 1) chunks = 1;
     long rpc = (M + chunks - 1) / chunks;
     rpc = (rpc + 31) / 32 * 32;
@@ -504,9 +542,10 @@ static int ensure_partial(ssd_train_state& s, size_t floats) {
 
 template <int OP>
 static int col_reduce(ssd_train_state& s, RedParams p, long* chunks_out, hipStream_t st) {
-    const int ctiles = (p.C + 63) / 64;
+    p.cw = p.C % 64 == 0 ? 64 : (p.C % 32 == 0 ? 32 : (p.C % 16 == 0 ? 16 : (p.C < 64 ? 32 : 64)));
+    const int ctiles = (p.C + p.cw - 1) / p.cw;
     long rpc = 0;
-    const long chunks = chunks_for(p.M, ctiles, &rpc, 64);
+    const long chunks = chunks_for(p.M, ctiles, &rpc, 64, 256);
     int rc = ensure_partial(s, (size_t)chunks * 2 * p.C);
     if (rc) return rc;
     p.rows_per_chunk = rpc;
@@ -518,7 +557,7 @@ static int col_reduce(ssd_train_state& s, RedParams p, long* chunks_out, hipStre
 }
 static int col_finalize(ssd_train_state& s, long chunks, int C, float scale, float* out1, float* out2, int mode,
                         hipStream_t st) {
-    hipLaunchKernelGGL(col_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, st, s.partial, (int)chunks, C, scale,
+    hipLaunchKernelGGL(col_finalize_kernel, dim3((C + 15) / 16), dim3(256), 0, st, s.partial, (int)chunks, C, scale,
                        out1, out2, mode, kBnEps);
     SSD_LAUNCH_CHECK();
     return SSD_OK;
@@ -575,7 +614,7 @@ static int wgrad(ssd_train_state& s, const Layer& l, int B, const float* x, cons
     p.vec_g = (ldg % 4 == 0) && (((uintptr_t)g & 15) == 0);
     const long tiles = (long)l.kh * l.kw * p.ctiles * p.ntiles;
     long rpc = 0;
-    long chunks = chunks_for(p.M, tiles, &rpc, 128);
+    long chunks = chunks_for(p.M, tiles, &rpc, 128, 1024);
     // bound the slab: chunks * K * N floats
     const size_t kn = (size_t)p.K * N;
     while (chunks > 1 && (size_t)chunks * kn > ((size_t)96 << 20)) {
@@ -588,7 +627,7 @@ static int wgrad(ssd_train_state& s, const Layer& l, int B, const float* x, cons
     p.partial = s.partial;
     hipLaunchKernelGGL(wgrad_mfma_kernel, dim3((unsigned)tiles, (unsigned)chunks), dim3(256), 0, st, p);
     SSD_LAUNCH_CHECK();
-    hipLaunchKernelGGL(chunk_sum_kernel, dim3(grid_for((long)kn)), dim3(256), 0, st, s.partial, (int)chunks, (long)kn, dW);
+    hipLaunchKernelGGL(chunk_sum_kernel, dim3(grid_for((long)kn * 4)), dim3(256), 0, st, s.partial, (int)chunks, (long)kn, dW);
     SSD_LAUNCH_CHECK();
     return SSD_OK;
 }
@@ -928,13 +967,13 @@ int ssd_net_train_forward_backward(ssd_net* net, const float* image_dev, int B, 
             dp.accumulate = s.gwritten[l.in];
             const int ctiles = (l.Cin + 63) / 64;
             long rpc = 0;
-            const long chunks = chunks_for(M, ctiles, &rpc, 64);
+            const long chunks = chunks_for(M, ctiles, &rpc, 64, 2048);
             rc = ensure_partial(s, (size_t)chunks * 9 * l.Cin);
             if (rc) return rc;
             dp.rows_per_chunk = rpc;
             dp.partial = s.partial;
             hipLaunchKernelGGL(dw_wgrad_kernel, dim3(ctiles, (unsigned)chunks), dim3(256), 0, st, dp);
-            hipLaunchKernelGGL(chunk_sum_kernel, dim3(grid_for(9L * l.Cin)), dim3(256), 0, st, s.partial, (int)chunks,
+            hipLaunchKernelGGL(chunk_sum_kernel, dim3(grid_for(36L * l.Cin)), dim3(256), 0, st, s.partial, (int)chunks,
                                9L * l.Cin, grads_flat_dev + t.g_kernel);
             hipLaunchKernelGGL(dw_dgrad_kernel, dim3(grid_for((long)B * l.H * l.W * (l.Cin / 4))), dim3(256), 0, st, dp);
             SSD_LAUNCH_CHECK();
