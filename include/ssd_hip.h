@@ -180,6 +180,18 @@ int ssd_conv2d_ex(const ssd_conv_desc* d, const float* in_dev, const float* pack
                   float* out_dev, long out_batch_stride, long out_pixel_stride, int config,
                   int split_k, float* splitk_ws_dev, void* stream);
 
+/* Winograd F(2x2,3x3) variant of the same op for 3x3 stride-1 dilation-1 convs with Cin % 16 == 0
+ * (the SSD head convs, models/header.py:60-61, and VGG16's 3x3 backbone, models/ssd_vgg16.py:52-72):
+ * 2.25x fewer multiplications on the same fp32 MFMA, fused input / output transforms.  Weights are
+ * transformed once ([16][Npad][Cin] floats).  The graph runner's autotune picks it per layer. */
+size_t ssd_conv_wino_weight_floats(int Cin, int Cout);
+int ssd_conv_wino_pack_weights(const float* hwio_dev, int Cin, int Cout, float* wino_w_dev, void* stream);
+int ssd_conv_wino_num_configs(void);
+int ssd_conv2d_wino(const ssd_conv_desc* d, const float* in_dev, const float* wino_w_dev,
+                    const float* scale_dev, const float* shift_dev, float* out_dev,
+                    long out_batch_stride, long out_pixel_stride, int wino_config, int split_k,
+                    float* splitk_ws_dev, void* stream);
+
 /* DepthwiseConv2D 3x3 (+BN +act): weights [3,3,C] (Keras [3,3,C,1]) device (K2). */
 int ssd_dwconv3x3(const float* in_dev, int B, int H, int W, int C, int stride,
                   int pad_t, int pad_l, int pad_b, int pad_r,

@@ -532,3 +532,78 @@ def test_get_head_from_outputs_composition():
     assert hw.get_config() == {"name": "labels_head", "last_dimension": 5}
     with pytest.raises(ValueError):
         header.get_head_from_outputs(hp, feats[:3])
+
+
+WINO_CASES = [
+    # (B, H, W, Cin, Cout, padding)
+    (2, 19, 19, 64, 100, "same"),       # head level 1 geometry (odd size: half tiles at the border), Cout = A*(L+4)
+    (3, 10, 10, 128, 150, "same"),      # head level 2, Cout % 4 != 0 -> scalar stores
+    (2, 5, 5, 48, 150, "same"),
+    (4, 1, 1, 32, 100, "same"),         # 1x1 feature map: a single quarter tile
+    (2, 2, 3, 16, 24, "same"),
+    (1, 38, 38, 64, 64, "same"),        # VGG-like
+    (2, 5, 5, 32, 40, "valid"),         # VGG conv10_2 / conv11_2: VALID 3x3
+    (1, 7, 9, 16, 20, (2, 0, 0, 2)),    # asymmetric explicit pads
+]
+
+
+@pytest.mark.parametrize("case", WINO_CASES)
+def test_conv2d_winograd_all_configs(case):
+    """Winograd F(2x2,3x3) kernels (csrc/ssd_wino.hip) vs the NumPy oracle for every tile
+    configuration, with and without the channel split, scale/shift/activation epilogue, strided
+    destination; NaN-poisoned surroundings catch out-of-bounds reads."""
+    import ssd_hip as h
+    lib = h.lib()
+    B, H, W, Cin, Cout, padding = case
+    rng = np.random.default_rng(abs(hash(case[:5])) % 1000)
+    x = rng.standard_normal((B, H, W, Cin)).astype(np.float32)
+    w = (rng.standard_normal((3, 3, Cin, Cout)) / np.sqrt(9 * Cin)).astype(np.float32)
+    scale = rng.uniform(0.5, 1.5, Cout).astype(np.float32)
+    shift = rng.uniform(-0.5, 0.5, Cout).astype(np.float32)
+    if padding == "same":
+        pads = same(H, 3, 1) + same(W, 3, 1)
+        ref = no.conv2d(x, w, None, 1, 1, "same")
+    elif padding == "valid":
+        pads = (0, 0, 0, 0)
+        ref = no.conv2d(x, w, None, 1, 1, "valid")
+    else:
+        pads = padding
+        ref = no.conv2d(x, w, None, 1, 1, pads)
+    ref = no.relu6(ref * scale + shift)
+    Ho, Wo = ref.shape[1], ref.shape[2]
+    d = h.ConvDesc(B, H, W, Cin, Cout, 3, 3, 1, 1, pads[0], pads[2], pads[1], pads[3], 2, 0)
+    xd, wd = guarded(x), h.to_dev(w)
+    nu = lib.ssd_conv_wino_weight_floats(Cin, Cout)
+    poisoned = torch.full((nu + 4096,), float("nan"), dtype=torch.float32, device=xd.device)
+    U = poisoned[:nu]
+    h.check(lib.ssd_conv_wino_pack_weights(h.ptr(wd), Cin, Cout, h.ptr(U), h.stream()), "wino pack")
+    sd, hd = guarded(scale), guarded(shift)
+    worst = 0.0
+    for cfg in range(lib.ssd_conv_wino_num_configs()):
+        for sk in (1, 2, 3):
+            if sk > Cin // 16:
+                continue
+            out = torch.full((B, Ho, Wo, Cout), float("nan"), dtype=torch.float32, device=xd.device)
+            ws = torch.full((max(1, sk * B * Ho * Wo * Cout),), float("nan"), dtype=torch.float32, device=xd.device) if sk > 1 else None
+            rc = lib.ssd_conv2d_wino(ctypes.byref(d), h.ptr(xd), h.ptr(U), h.ptr(sd), h.ptr(hd), h.ptr(out), 0, 0, cfg, sk,
+                                     h.ptr(ws), h.stream())
+            assert rc == 0, (cfg, sk, lib.ssd_last_error())
+            err = float(np.abs(_np(out) - ref).max())
+            worst = max(worst, err)
+            assert err <= 2e-5 * max(1.0, float(np.abs(ref).max())), (cfg, sk, err)
+    # strided destination (the concatenated head buffer): level slab inside a NaN canvas
+    total = B * (Ho * Wo * Cout + 77) + 13
+    canvas = torch.full((total,), float("nan"), dtype=torch.float32, device=xd.device)
+    off = 12 if Cout % 4 == 0 else 13
+    rc = lib.ssd_conv2d_wino(ctypes.byref(d), h.ptr(xd), h.ptr(U), h.ptr(sd), h.ptr(hd), h.vp(canvas.data_ptr() + 4 * off),
+                             Ho * Wo * Cout + 77, Cout, 0, 1, None, h.stream())
+    assert rc == 0
+    c = _np(canvas)
+    for b in range(B):
+        s0 = off + b * (Ho * Wo * Cout + 77)
+        np.testing.assert_allclose(c[s0:s0 + Ho * Wo * Cout].reshape(Ho, Wo, Cout), ref[b], atol=2e-5 * max(1.0, float(np.abs(ref).max())))
+        assert np.isnan(c[s0 + Ho * Wo * Cout:s0 + Ho * Wo * Cout + 77 - (0 if b < B - 1 else 77 - 1)]).all()
+    print("winograd worst abs err %.2e (max |ref| %.2f)" % (worst, float(np.abs(ref).max())))
+    # not applicable: stride 2 / Cin % 16 != 0
+    bad = h.ConvDesc(B, H, W, Cin, Cout, 3, 3, 2, 1, 1, 1, 1, 1, 0, 0)
+    assert lib.ssd_conv2d_wino(ctypes.byref(bad), h.ptr(xd), h.ptr(U), None, None, h.ptr(out), 0, 0, 0, 1, None, h.stream()) == -3

@@ -29,6 +29,7 @@ struct ConvParams {
     int vec_store;         // 1: float4 stores are aligned
     int split_k;           // >1: partial sums to `partial` [split][M][Cout], epilogue deferred
     float* partial;
+    const float* wino_w;   // Winograd F(2x2,3x3) weights U [16][Npad][Cin] (ssd_wino.hip) or nullptr
 };
 
 // One fused MobileNetV2 inverted-residual block (csrc/ssd_fused.hip).
@@ -99,6 +100,19 @@ int conv_launch(const ConvParams& p, int cfg, hipStream_t st);
 size_t conv_splitk_workspace_floats(const ConvParams& p, int cfg);
 
 int fill_conv_params(const ssd_conv_desc* d, ConvParams* p);   // geometry + validation
+int launch_splitk_reduce(const ConvParams& p, hipStream_t st);
+
+// Winograd F(2x2, 3x3) path (csrc/ssd_wino.hip): config ids [conv_num_mfma_configs(), +wino_num_configs())
+int conv_num_mfma_configs();
+int wino_num_configs();
+const char* wino_config_name(int i);
+bool wino_applicable(const ConvParams& p);
+bool wino_config_valid(int i, const ConvParams& p);
+long wino_grid_blocks(int i, const ConvParams& p);
+int wino_k_tiles(const ConvParams& p);
+int wino_launch(const ConvParams& p, int i, hipStream_t st);
+size_t wino_weight_floats(int Cin, int Cout);
+int launch_wino_pack(const float* hwio, int Cin, int Cout, int Npad, int row_off, float* U, hipStream_t st);
 
 int launch_dwconv3x3(const float* in, int B, int H, int W, int C, int stride, int pad_t, int pad_l,
                      int Ho, int Wo, const float* w, const float* scale, const float* shift, int act,

@@ -613,11 +613,16 @@ static const ConvCfg kCfgs[] = {
     CFG(2, 10, 2, 2, 32),  // 64 x 320
 };
 constexpr int kNumMfmaCfgs = sizeof(kCfgs) / sizeof(kCfgs[0]);
-constexpr int kDirectCfg = kNumMfmaCfgs;       // last config id = VALU direct kernel
+// config ids: [0, kNumMfmaCfgs) implicit-GEMM tiles, then the Winograd F(2x2,3x3) tiles
+// (csrc/ssd_wino.hip), last = VALU direct kernel
+static int direct_cfg() { return kNumMfmaCfgs + wino_num_configs(); }
+#define kDirectCfg direct_cfg()
 
-int conv_num_configs() { return kNumMfmaCfgs + 1; }
+int conv_num_mfma_configs() { return kNumMfmaCfgs; }
+int conv_num_configs() { return kNumMfmaCfgs + wino_num_configs() + 1; }
 const char* conv_config_name(int cfg) {
     if (cfg == kDirectCfg) return "direct_valu";
+    if (cfg >= kNumMfmaCfgs && cfg < kDirectCfg) return wino_config_name(cfg - kNumMfmaCfgs);
     if (cfg < 0 || cfg >= kNumMfmaCfgs) return "?";
     return kCfgs[cfg].name;
 }
@@ -628,6 +633,7 @@ static bool is_gemm1x1(const ConvParams& p) {
 
 bool conv_config_valid(int cfg, const ConvParams& p) {
     if (cfg == kDirectCfg) return (size_t)p.K * ((p.Cout + 3) & ~3) * 4 <= 64 * 1024;
+    if (cfg >= kNumMfmaCfgs && cfg < kDirectCfg) return wino_config_valid(cfg - kNumMfmaCfgs, p);
     if (cfg < 0 || cfg >= kNumMfmaCfgs) return false;
     if (((uintptr_t)p.in & 15) || ((uintptr_t)p.w & 15)) return false;
     if (p.Cin % 4) return false;
@@ -660,11 +666,13 @@ int conv_pick_config(const ConvParams& p) {
 }
 
 long conv_grid_blocks(int cfg, const ConvParams& p) {
+    if (cfg >= kNumMfmaCfgs && cfg < kDirectCfg) return wino_grid_blocks(cfg - kNumMfmaCfgs, p);
     if (cfg < 0 || cfg >= kNumMfmaCfgs) return 0;
     const ConvCfg& g = kCfgs[cfg];
     return ((p.M + g.BM - 1) / g.BM) * ((p.Cout + g.BN - 1) / g.BN);
 }
 int conv_k_tiles(int cfg, const ConvParams& p) {
+    if (cfg >= kNumMfmaCfgs && cfg < kDirectCfg) return wino_k_tiles(p);
     if (cfg < 0 || cfg >= kNumMfmaCfgs) return 0;
     return (p.K + kCfgs[cfg].BK - 1) / kCfgs[cfg].BK;
 }
@@ -679,6 +687,11 @@ int conv_launch(const ConvParams& p, int cfg, hipStream_t st) {
         set_error("conv2d: config %d (%s) cannot run Cin=%d k=%dx%d stride=%d", cfg, conv_config_name(cfg),
                   p.Cin, p.kh, p.kw, p.stride);
         return SSD_E_UNSUPPORTED;
+    }
+    if (cfg >= kNumMfmaCfgs && cfg < kDirectCfg) {
+        const int rc = wino_launch(p, cfg - kNumMfmaCfgs, st);
+        if (rc || p.split_k <= 1) return rc;
+        return launch_splitk_reduce(p, st);
     }
     if (cfg == kDirectCfg && stem_ok(p)) {
         constexpr int PX = 2;
@@ -704,15 +717,18 @@ int conv_launch(const ConvParams& p, int cfg, hipStream_t st) {
     conv_kernel_t k = is_gemm1x1(p) ? g.gemm : g.general;
     hipLaunchKernelGGL(k, grid, dim3(256), 0, st, p);
     SSD_LAUNCH_CHECK();
-    if (p.split_k > 1) {
-        const long total = p.M * p.Cout;
-        const bool vec = (total % 4 == 0) && (((uintptr_t)p.partial & 15) == 0);
-        const long groups = vec ? total / 4 : total;
-        const int blocks = (int)(cdiv(groups, 256) < 8192 ? cdiv(groups, 256) : 8192);
-        if (vec) hipLaunchKernelGGL(splitk_reduce_kernel<4>, dim3(blocks), dim3(256), 0, st, p);
-        else hipLaunchKernelGGL(splitk_reduce_kernel<1>, dim3(blocks), dim3(256), 0, st, p);
-        SSD_LAUNCH_CHECK();
-    }
+    if (p.split_k > 1) return launch_splitk_reduce(p, st);
+    return SSD_OK;
+}
+
+int launch_splitk_reduce(const ConvParams& p, hipStream_t st) {
+    const long total = p.M * p.Cout;
+    const bool vec = (total % 4 == 0) && (((uintptr_t)p.partial & 15) == 0);
+    const long groups = vec ? total / 4 : total;
+    const int blocks = (int)(cdiv(groups, 256) < 8192 ? cdiv(groups, 256) : 8192);
+    if (vec) hipLaunchKernelGGL(splitk_reduce_kernel<4>, dim3(blocks), dim3(256), 0, st, p);
+    else hipLaunchKernelGGL(splitk_reduce_kernel<1>, dim3(blocks), dim3(256), 0, st, p);
+    SSD_LAUNCH_CHECK();
     return SSD_OK;
 }
 
@@ -814,6 +830,44 @@ int ssd_conv2d_ex(const ssd_conv_desc* d, const float* in_dev, const float* pack
     const int cfg = config >= 0 ? config : conv_pick_config(p);
     SSD_UNSUPPORTED_IF(cfg < 0, "conv2d: no kernel for Cin=%d Cout=%d k=%dx%d", p.Cin, p.Cout, p.kh, p.kw);
     if (cfg == conv_num_configs() - 1) p.split_k = 1;
+    return conv_launch(p, cfg, (hipStream_t)stream);
+}
+
+size_t ssd_conv_wino_weight_floats(int Cin, int Cout) {
+    if (Cin < 1 || Cout < 1) return 0;
+    return wino_weight_floats(Cin, Cout);
+}
+
+int ssd_conv_wino_pack_weights(const float* hwio_dev, int Cin, int Cout, float* wino_w_dev, void* stream) {
+    SSD_CHECK_ARG(hwio_dev && wino_w_dev && Cin >= 1 && Cout >= 1, "ssd_conv_wino_pack_weights: bad arguments");
+    SSD_HIP(hipMemsetAsync(wino_w_dev, 0, wino_weight_floats(Cin, Cout) * sizeof(float), (hipStream_t)stream));
+    return launch_wino_pack(hwio_dev, Cin, Cout, conv_npad(Cout), 0, wino_w_dev, (hipStream_t)stream);
+}
+
+int ssd_conv_wino_num_configs(void) { return wino_num_configs(); }
+
+int ssd_conv2d_wino(const ssd_conv_desc* d, const float* in_dev, const float* wino_w_dev, const float* scale_dev,
+                    const float* shift_dev, float* out_dev, long out_batch_stride, long out_pixel_stride,
+                    int wino_config, int split_k, float* splitk_ws_dev, void* stream) {
+    ConvParams p;
+    int rc = fill_conv_params(d, &p);
+    if (rc) return rc;
+    if (p.M == 0) return SSD_OK;
+    SSD_CHECK_ARG(in_dev && wino_w_dev && out_dev, "conv2d_wino: NULL pointer");
+    SSD_CHECK_ARG(!d->has_residual, "conv2d_wino: residual is not supported");
+    p.in = in_dev; p.wino_w = wino_w_dev; p.scale = scale_dev; p.shift = shift_dev;
+    p.out = out_dev;
+    p.out_pixel_stride = out_pixel_stride > 0 ? out_pixel_stride : p.Cout;
+    p.out_batch_stride = out_batch_stride > 0 ? out_batch_stride : (long)p.Ho * p.Wo * p.out_pixel_stride;
+    p.vec_store = (((uintptr_t)out_dev & 15) == 0) && (p.out_pixel_stride % 4 == 0) && (p.out_batch_stride % 4 == 0);
+    if (split_k > 1) {
+        SSD_CHECK_ARG(splitk_ws_dev != nullptr, "conv2d_wino: split_k > 1 needs a workspace");
+        SSD_CHECK_ARG(split_k <= p.Cin / 16, "conv2d_wino: split_k %d exceeds the %d channel slabs", split_k, p.Cin / 16);
+        p.split_k = split_k;
+        p.partial = splitk_ws_dev;
+    }
+    SSD_UNSUPPORTED_IF(!wino_applicable(p), "conv2d_wino: needs a 3x3 stride-1 dilation-1 conv with Cin %% 16 == 0");
+    const int cfg = conv_num_mfma_configs() + (wino_config >= 0 ? wino_config : 0);
     return conv_launch(p, cfg, (hipStream_t)stream);
 }
 

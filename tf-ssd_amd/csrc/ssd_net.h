@@ -47,6 +47,7 @@ struct Layer {
     long head2_off = 0, head2_bs = 0, head2_ps = 0;
     // derived at finalize
     float* packed = nullptr;
+    float* wino = nullptr;          // Winograd F(2x2,3x3) weights (3x3 stride-1 convs), see ssd_wino.hip
     float* scale = nullptr;
     float* shift = nullptr;
     int cfg = -1;
@@ -81,6 +82,7 @@ struct ssd_net {
     bool finalized = false;
     bool fuse_blocks = true;        // run eligible inverted-residual blocks as one fused kernel
     bool fuse_dwproj = true;        // ... and depthwise + project of the others as one kernel
+    bool use_wino = true;           // offer the Winograd F(2x2,3x3) kernels to the autotune
     int max_batch = 0;
     int last_batch = 0;
     std::vector<float*> owned;      // device allocations to free

@@ -302,6 +302,7 @@ static ConvParams layer_conv_params(const ssd_net& net, const Layer& l, int B, c
     ConvParams p{};
     p.in = in;
     p.w = l.packed;
+    p.wino_w = l.wino;
     p.scale = l.scale;
     p.shift = l.shift;
     p.residual = res;
@@ -687,6 +688,7 @@ int ssd_net_finalize(ssd_net* net, int max_batch) {
     net->splitk_layers = nullptr;
     for (auto& l : net->layers) {
         l.packed = l.scale = l.shift = nullptr;
+        l.wino = nullptr;
         l.splitk_part = nullptr;        // autotune runs on the shared slab; per-layer slabs are re-planned below
         if (l.kind == LK_CONV) {
             const int K = l.kh * l.kw * l.Cin;
@@ -703,6 +705,20 @@ int ssd_net_finalize(ssd_net* net, int max_batch) {
                                              l.Cout - l.Cout1, l.packed + (size_t)l.Cout1 * conv_kpad(K), st);
             }
             if (rc) return rc;
+            // Winograd form of the 3x3 stride-1 convs (heads, VGG16 backbone): the autotune decides
+            if (l.kh == 3 && l.kw == 3 && l.stride == 1 && l.dil == 1 && l.Cin % 16 == 0 && l.res < 0 && net->use_wino) {
+                const int np = conv_npad(l.Cout);
+                rc = dev_alloc(*net, wino_weight_floats(l.Cin, l.Cout), &l.wino);
+                if (rc) return rc;
+                SSD_HIP(hipMemsetAsync(l.wino, 0, wino_weight_floats(l.Cin, l.Cout) * sizeof(float), st));
+                if (l.p_kernel2 < 0) {
+                    rc = launch_wino_pack(net->params[l.p_kernel].dev, l.Cin, l.Cout, np, 0, l.wino, st);
+                } else {
+                    rc = launch_wino_pack(net->params[l.p_kernel].dev, l.Cin, l.Cout1, np, 0, l.wino, st);
+                    if (!rc) rc = launch_wino_pack(net->params[l.p_kernel2].dev, l.Cin, l.Cout - l.Cout1, np, l.Cout1, l.wino, st);
+                }
+                if (rc) return rc;
+            }
         }
         if (l.kind == LK_CONV || l.kind == LK_DW) {
             if (l.p_bn >= 0) {
@@ -1083,6 +1099,12 @@ int ssd_net_set_option(ssd_net* net, const char* name, int value) {
     }
     if (std::string(name) == "overlap_heads") {
         net->overlap_heads = value != 0;
+        net->drop_graphs();
+        return SSD_OK;
+    }
+    if (std::string(name) == "use_wino") {       // Winograd F(2x2,3x3) candidates in the autotune (default 1)
+        net->use_wino = value != 0;
+        net->finalized = false;
         net->drop_graphs();
         return SSD_OK;
     }

@@ -60,6 +60,11 @@ _SIGNATURES = {
     "ssd_conv_config_name": (ctypes.c_char_p, [ctypes.c_int]),
     "ssd_conv2d_ex": (ctypes.c_int, [ctypes.POINTER(ConvDesc), vp, vp, vp, vp, vp, vp,
                                      ctypes.c_long, ctypes.c_long, ctypes.c_int, ctypes.c_int, vp, vp]),
+    "ssd_conv_wino_weight_floats": (ctypes.c_size_t, [ctypes.c_int, ctypes.c_int]),
+    "ssd_conv_wino_pack_weights": (ctypes.c_int, [vp, ctypes.c_int, ctypes.c_int, vp, vp]),
+    "ssd_conv_wino_num_configs": (ctypes.c_int, []),
+    "ssd_conv2d_wino": (ctypes.c_int, [ctypes.POINTER(ConvDesc), vp, vp, vp, vp, vp, ctypes.c_long, ctypes.c_long,
+                                       ctypes.c_int, ctypes.c_int, vp, vp]),
     "ssd_dwconv3x3": (ctypes.c_int, [vp] + [ctypes.c_int] * 9 + [vp, vp, vp, ctypes.c_int, vp, vp]),
     "ssd_maxpool2d": (ctypes.c_int, [vp] + [ctypes.c_int] * 10 + [vp, vp]),
     "ssd_l2norm": (ctypes.c_int, [vp, ctypes.c_long, ctypes.c_int, vp, vp, vp]),
