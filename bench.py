@@ -128,9 +128,12 @@ def main():
         decoder_model(x)
     info, nfw = model.read_timing(B)
     model.set_timing(False)
-    mfma = [r for r in info if r["kind"] == "conv" and r["config"].startswith("mfma_") and r["flops"] > 0]
+    # the dense-conv family on the fp32 matrix cores: implicit-GEMM tiles and Winograd F(2x2,3x3) tiles
+    mfma = [r for r in info if r["kind"] == "conv" and r["config"].startswith(("mfma_", "wino_")) and r["flops"] > 0]
     mfma_ms = sum(r["ms"] for r in mfma)
     mfma_flops = sum(r["flops"] for r in mfma)
+    mfma_exec = sum(r["executed_flops"] for r in mfma)
+    wino = [r for r in mfma if r["config"].startswith("wino_")]
     total_ms = sum(r["ms"] for r in info if r["flops"] > 0 or r["bytes"] > 0 or r["kind"] == "nms")
     kinds = {}
     for r in info:
@@ -193,9 +196,17 @@ def main():
                        (1 if args.backbone == "mobilenet_v2" else 2) if hp["img_size"] == 300 else 4),
                    "global_batch": world * B, "priors": model.num_priors, "labels": hp["total_labels"],
                    "mean_detections_per_image": mean_det, "nms_active": mean_det > 0, "parallelism": "batch-sharded x%d, no collective" % world},
-        "roofline": {"bound": "mfma", "kernel": "conv_mfma_kernel (fp32 v_mfma_f32_16x16x4 implicit-GEMM conv, all tile configs)",
+        "roofline": {"bound": "mfma", "kernel": "conv_mfma_kernel + conv_wino_kernel (fp32 v_mfma_f32_16x16x4: implicit-GEMM and "
+                                                 "Winograd F(2x2,3x3) tiles, all configs)",
+                     # `achieved` counts ALGORITHMIC conv FLOPs (MACs x 2 of the direct
+                     # convolution); Winograd layers issue 2.25x fewer, so it may exceed `peak` --
+                     # `achieved_executed` / `frac_executed` count what the matrix cores really ran
                      "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                     "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": traffic, "traffic_detail": traffic_detail,
+                     "frac": achieved / PEAK_FP32_MFMA_TFLOPS,
+                     "achieved_executed": mfma_exec / (mfma_ms * 1e-3) / 1e12 if mfma_ms > 0 else 0.0,
+                     "frac_executed": (mfma_exec / (mfma_ms * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS) if mfma_ms > 0 else 0.0,
+                     "winograd_layers": len(wino), "winograd_ms_per_step": sum(r["ms"] for r in wino),
+                     "traffic": traffic, "traffic_detail": traffic_detail,
                      "launches_per_step": len(mfma), "kernel_ms_per_step": mfma_ms,
                      "algorithmic_gflop_per_step": mfma_flops / 1e9,
                      # the whole step (every kernel, incl. softmax/decode/NMS time) against the same peak

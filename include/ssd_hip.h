@@ -265,13 +265,16 @@ const char* ssd_net_layer_kind(const ssd_net* net, int i);   /* "conv","dw","poo
 const char* ssd_net_layer_config(const ssd_net* net, int i); /* autotuned conv tile config */
 double ssd_net_layer_flops(const ssd_net* net, int i, int B); /* 2*MACs                  */
 double ssd_net_layer_bytes(const ssd_net* net, int i, int B); /* in + out + weights      */
+/* FLOPs the chosen kernel issues: = layer_flops except Winograd layers (x 16/36, whole border tiles) */
+double ssd_net_layer_executed_flops(const ssd_net* net, int i, int B);
 /* Options: "use_graph" (default 1) replays each forward/predict step as one captured hipGraph
  * (keyed by the pointers/sizes of the call; streams other than the NULL stream only);
  * "fuse_blocks" (default 1) runs eligible MobileNetV2 inverted-residual blocks
  * (expand -> depthwise -> project) as one fused kernel; 0 runs them as three layers (then
  * every intermediate activation is inspectable); "fuse_dwproj" (default 1, needs fuse_blocks)
  * runs depthwise -> project of the remaining blocks (7-16) as one kernel behind the expand
- * GEMM; "overlap_heads" (default 1) runs the SSD head convs on a side stream. */
+ * GEMM; "overlap_heads" (default 1) runs the SSD head convs on a side stream; "use_wino" (default 1)
+ * offers the Winograd F(2x2,3x3) kernels to finalize's autotune for the 3x3 stride-1 convs. */
 int ssd_net_set_option(ssd_net* net, const char* name, int value);
 /* Diagnostics: per-phase mean cycles per wave of one fused block layer (clock64 inside the
  * kernel): prologue, expand, depthwise, project, weight staging, epilogue. */

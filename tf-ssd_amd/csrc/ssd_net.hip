@@ -1198,6 +1198,17 @@ double ssd_net_layer_flops(const ssd_net* net, int i, int B) {
     if (l.kind == LK_DW) return 2.0 * px * 9 * l.Cout;
     return 0;
 }
+// FLOPs the chosen kernel actually issues to the matrix cores: equal to the algorithmic figure
+// except for Winograd F(2x2,3x3) layers (16 multiplies per 2x2 tile and channel pair instead of 36;
+// border tiles are computed whole).
+double ssd_net_layer_executed_flops(const ssd_net* net, int i, int B) {
+    if (!net || i < 0 || i >= (int)net->layers.size()) return 0;
+    const Layer& l = net->layers[i];
+    if (!layer_runs(*net, l)) return 0;
+    if (l.kind == LK_CONV && l.cfg >= conv_num_mfma_configs() && l.cfg < conv_num_configs() - 1)
+        return 2.0 * B * ((l.Ho + 1) / 2) * ((l.Wo + 1) / 2) * 16.0 * l.Cin * l.Cout;
+    return ssd_net_layer_flops(net, i, B);
+}
 double ssd_net_layer_bytes(const ssd_net* net, int i, int B) {
     if (!net || i < 0 || i >= (int)net->layers.size()) return 0;
     const Layer& l = net->layers[i];

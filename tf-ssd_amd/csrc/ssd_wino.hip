@@ -63,7 +63,7 @@ __global__ __launch_bounds__(256) void wino_pack_kernel(const float* __restrict_
 }
 
 template <int NT, int WT, int WN>
-__global__ __launch_bounds__(256) void conv_wino_kernel(const ConvParams p) {
+__global__ __launch_bounds__(256, (NT <= 4 ? 2 : 1)) void conv_wino_kernel(const ConvParams p) {
     constexpr int TT = 16 * WT, TN = 16 * NT * WN, LDK = 24;      // 24-float rows: conflict-free b128 fragments
     constexpr int XI = TT * 4, XP = (XI + 255) / 256;             // input items (tile, channel quad)
     constexpr int WU = 4 * TN * 4, WP = (WU + 255) / 256;         // U units: 4 b x TN rows x 4 quads
@@ -145,7 +145,7 @@ __global__ __launch_bounds__(256) void conv_wino_kernel(const ConvParams p) {
 #pragma unroll
             for (int ni = 0; ni < NT; ++ni) acc[b][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-        f32x4 xr[XP][4], wr[WP];       // row-combined patch columns / U units of the slab in flight
+        f32x4 x1[XP][4], x2[XP][4], wr[WP];       // raw patch rows / U units of the slab in flight (combined at store time)
         auto load_slab = [&](int s) {
             const int ci0 = s * 16;
 #pragma unroll
@@ -157,7 +157,8 @@ __global__ __launch_bounds__(256) void conv_wino_kernel(const ConvParams p) {
                         v1 = *reinterpret_cast<const f32x4*>(p.in + xbase[ps] + r1 * rowstep + (long)cc * p.Cin + ci0);
                     if ((xmask[ps] >> (r2 * 4 + cc)) & 1u)
                         v2 = *reinterpret_cast<const f32x4*>(p.in + xbase[ps] + r2 * rowstep + (long)cc * p.Cin + ci0);
-                    xr[ps][cc] = v1 + sgn * v2;
+                    x1[ps][cc] = v1;
+                    x2[ps][cc] = v2;
                 }
             }
 #pragma unroll
@@ -170,11 +171,14 @@ __global__ __launch_bounds__(256) void conv_wino_kernel(const ConvParams p) {
                 const int it = tid + ps * 256;
                 if (XI % 256 != 0 && it >= XI) continue;
                 float* dst = Vs + (it >> 2) * LDK + (it & 3) * 4;
+                f32x4 c[4];
+#pragma unroll
+                for (int cc = 0; cc < 4; ++cc) c[cc] = x1[ps][cc] + sgn * x2[ps][cc];
                 // column transform (d B): b0: c0 - c2, b1: c1 + c2, b2: c2 - c1, b3: c1 - c3
-                *reinterpret_cast<f32x4*>(dst + 0 * TT * LDK) = xr[ps][0] - xr[ps][2];
-                *reinterpret_cast<f32x4*>(dst + 1 * TT * LDK) = xr[ps][1] + xr[ps][2];
-                *reinterpret_cast<f32x4*>(dst + 2 * TT * LDK) = xr[ps][2] - xr[ps][1];
-                *reinterpret_cast<f32x4*>(dst + 3 * TT * LDK) = xr[ps][1] - xr[ps][3];
+                *reinterpret_cast<f32x4*>(dst + 0 * TT * LDK) = c[0] - c[2];
+                *reinterpret_cast<f32x4*>(dst + 1 * TT * LDK) = c[1] + c[2];
+                *reinterpret_cast<f32x4*>(dst + 2 * TT * LDK) = c[2] - c[1];
+                *reinterpret_cast<f32x4*>(dst + 3 * TT * LDK) = c[1] - c[3];
             }
 #pragma unroll
             for (int ps = 0; ps < WP; ++ps) {
@@ -299,6 +303,9 @@ static const WinoCfg kWino[] = {
     WCFG(2, 2, 2),    // 32 x 64
     WCFG(8, 4, 1),    // 64 x 128
     WCFG(5, 4, 1),    // 64 x 80
+    WCFG(3, 4, 1),    // 64 x 48
+    WCFG(4, 1, 4),    // 16 x 256
+    WCFG(2, 4, 1),    // 64 x 32
 };
 constexpr int kNumWino = sizeof(kWino) / sizeof(kWino[0]);
 

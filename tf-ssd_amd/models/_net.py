@@ -210,6 +210,7 @@ class SSDModel(object):
                         "kind": lib.ssd_net_layer_kind(self._net, i).decode(),
                         "config": lib.ssd_net_layer_config(self._net, i).decode(),
                         "flops": lib.ssd_net_layer_flops(self._net, i, B),
+                        "executed_flops": lib.ssd_net_layer_executed_flops(self._net, i, B),
                         "bytes": lib.ssd_net_layer_bytes(self._net, i, B)})
         return out
 
@@ -340,7 +341,7 @@ class SSDModel(object):
         cnt = ctypes.c_int(0)
         _h.check(lib.ssd_net_read_timing(self._net, ms, ctypes.byref(cnt)), "read_timing")
         info = self.layers(B)
-        info.append({"name": "decode_nms", "kind": "nms", "config": "", "flops": 0.0, "bytes": 0.0})
+        info.append({"name": "decode_nms", "kind": "nms", "config": "", "flops": 0.0, "executed_flops": 0.0, "bytes": 0.0})
         k = max(cnt.value, 1)
         for i, rec in enumerate(info):
             rec["ms"] = float(ms[i]) / k

@@ -92,6 +92,7 @@ _SIGNATURES = {
     "ssd_net_layer_config": (ctypes.c_char_p, [vp, ctypes.c_int]),
     "ssd_net_layer_flops": (ctypes.c_double, [vp, ctypes.c_int, ctypes.c_int]),
     "ssd_net_layer_bytes": (ctypes.c_double, [vp, ctypes.c_int, ctypes.c_int]),
+    "ssd_net_layer_executed_flops": (ctypes.c_double, [vp, ctypes.c_int, ctypes.c_int]),
     "ssd_net_set_option": (ctypes.c_int, [vp, ctypes.c_char_p, ctypes.c_int]),
     "ssd_net_profile_fused": (ctypes.c_int, [vp, ctypes.c_char_p, ctypes.c_int, ctypes.POINTER(ctypes.c_double)]),
     "ssd_net_set_timing": (ctypes.c_int, [vp, ctypes.c_int]),
