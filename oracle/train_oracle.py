@@ -41,6 +41,21 @@ def mobilenet_v2_act_names():
     return names
 
 
+def vgg16_act_names():
+    """Names of the ReLU outputs of the VGG16-SSD graph in call order (models/ssd_vgg16.py:52-91)."""
+    names = [n for n, _, _ in no._VGG] + ["conv6", "conv7"]
+    for i in range(8, 12):
+        names += ["conv%d_1" % i, "conv%d_2" % i]
+    return names
+
+
+def act_names(backbone):
+    return mobilenet_v2_act_names() if backbone == "mobilenet_v2" else vgg16_act_names()
+
+
+L2_REG = 5e-4       # models/ssd_vgg16.py:45: kernel_regularizer=l2(5e-4) on the backbone / extra convs
+
+
 class TrainOps(tg.TorchOps):
     """tg.TorchOps with differentiable training-mode ops; tensors stay tensors."""
     moving = None       # list of (moving_mean tensor, new mean, moving_var tensor, new var)
@@ -109,7 +124,12 @@ def train_step(backbone, hyper_params, P, x, actual_deltas, actual_labels, neg_p
     yd = torch.from_numpy(np.asarray(actual_deltas, np.float32))
     yl = torch.from_numpy(np.asarray(actual_labels, np.float32))
     loc, conf = lo.torch_loss(yd, yl, deltas, probs, neg_pos_ratio, loc_loss_alpha, final_mask)
-    (loc + conf).mean().backward()
+    total = (loc + conf).mean()
+    if backbone == "vgg16":        # Keras adds the layers' regularisation losses to the objective
+        for name, t in T.items():
+            if name.endswith("/kernel") and not name[0].isdigit():
+                total = total + L2_REG * (t * t).sum()
+    total.backward()
     ids = {id(t): n for n, t in T.items()}
     moving = {}
     for mm, mu, mv, va in TrainOps.moving:

@@ -206,6 +206,60 @@ def test_train_step_matches_autograd_oracle():
 
 
 @pytest.mark.gpu
+def test_train_step_vgg16_matches_autograd_oracle():
+    """The same check on the VGG16 graph (bias + ReLU convs incl. dilation 6 / VALID / stride 2,
+    SAME max-pools incl. the overlapping 3x3 stride-1 pool5, L2Normalization with its learnable
+    scale, l2(5e-4) kernel regulariser)."""
+    import torch
+    from models.ssd_vgg16 import get_model
+    from oracle import train_oracle as to
+    from ssd_loss import CustomLoss
+    hp = helpers.hyper_params("vgg16")
+    w = {k: v.copy() for k, v in helpers.synthetic_weights("vgg16", hp).items()}
+    B = 2
+    x = helpers.images(B, 300, seed=23)
+    yd, yl = _targets(hp, B, seed=4)
+    m = get_model(hp)
+    m.set_weights(w)
+    cl = CustomLoss(hp["neg_pos_ratio"], hp["loc_loss_alpha"])
+    m.compile(loss=[cl.loc_loss_fn, cl.conf_loss_fn])
+    loc, conf, g = m.forward_backward(x, yd, yl)
+    loc, conf, g = loc.cpu().numpy(), conf.cpu().numpy(), g.cpu().numpy().copy()
+    probs = m.train_fetch("probs", B).reshape(B, -1, hp["total_labels"])
+    cl.conf_loss_fn(yl, probs)
+    fm = cl.last_final_mask.cpu().numpy()
+    masks = []
+    for name in to.act_names("vgg16"):
+        a = m.train_fetch(name, B)
+        masks.append((a > 0).reshape(B, *_hwc(m, name)))
+    torch.set_num_threads(min(16, torch.get_num_threads()))
+    ref = to.train_step("vgg16", hp, w, x, yd, yl, 3.0, 1.0, final_mask=fm, act_masks=masks)
+    assert np.abs(probs - ref["probs"]).max() <= 1e-4
+    np.testing.assert_allclose(loc, ref["loc"], rtol=1e-4, atol=1e-6)
+    np.testing.assert_allclose(conf, ref["conf"], rtol=1e-4, atol=1e-6)
+    offs = m.trainable_offsets()
+    assert set(offs) == set(ref["grads"])
+    errs = []
+    for name, (off, shape) in offs.items():
+        got = g[off:off + int(np.prod(shape))].reshape(shape)
+        rg = ref["grads"][name]
+        scale = max(float(np.abs(rg).max()), 1e-2)
+        errs.append((float(np.abs(got - rg).max()) / scale, name, scale))
+    for e in sorted(errs)[-6:]:
+        print("grad %-42s err %.2e of max(|g|max, 1e-2) = %.3e" % (e[1], e[0], e[2]))
+    # (a max-pool arg-max that flips between two nearly equal activations moves single entries;
+    # the bulk criterion is the L2 norm, the max-norm bound is looser than for MobileNetV2)
+    for name, (off, shape) in offs.items():
+        got = g[off:off + int(np.prod(shape))].reshape(shape)
+        rg = ref["grads"][name]
+        assert np.linalg.norm(got - rg) <= 2e-3 * np.linalg.norm(rg) + 1e-6, name
+    assert max(errs)[0] <= 2e-2, max(errs)
+    m.apply_gradients(m._grads, learning_rate=LR)
+    loc2, conf2, _ = m.forward_backward(x, yd, yl)
+    assert float((loc2 + conf2).mean()) < float((loc + conf).mean())
+
+
+@pytest.mark.gpu
 def test_trainer_entry_point_fit(tmp_path, monkeypatch, capsys):
     """trainer.py: fit loop with LR schedule, validation, best-val_loss checkpoint (reference
     trainer.py:57-76) on a few synthetic steps; the checkpoint is a Keras-layout HDF5 file the

@@ -435,6 +435,85 @@ __global__ __launch_bounds__(256) void dw_dgrad_kernel(const DwBwdParams p) {
     }
 }
 
+// ------------------------------------------------------------------ max pool / L2 normalisation backward
+// MaxPool2D backward, gather form (deterministic, also for the overlapping 3x3 stride-1 pool5): an
+// input element receives dY of every window whose FIRST maximum (row-major scan over the valid
+// cells -- TF ignores padded cells) it is.
+struct PoolBwdParams {
+    const float* x;      // [B,H,W,C] forward input
+    const float* g;      // [B,Ho,Wo,C]
+    float* dx;
+    int B, H, W, C, Ho, Wo, k, stride, pad_t, pad_l, accumulate;
+};
+__global__ __launch_bounds__(256) void maxpool_bwd_kernel(const PoolBwdParams p) {
+    const long total = (long)p.B * p.H * p.W * p.C;
+    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+        const int c = (int)(e % p.C);
+        long r = e / p.C;
+        const int ix = (int)(r % p.W);
+        r /= p.W;
+        const int iy = (int)(r % p.H), b = (int)(r / p.H);
+        const float* xb = p.x + (long)b * p.H * p.W * p.C + c;
+        float acc = 0.f;
+        // windows containing (iy, ix): oy*s - pt <= iy <= oy*s - pt + k - 1
+        const int oy_lo = max(0, (iy + p.pad_t - p.k + 1 + p.stride - 1) / p.stride);
+        const int ox_lo = max(0, (ix + p.pad_l - p.k + 1 + p.stride - 1) / p.stride);
+        for (int oy = oy_lo; oy < p.Ho && oy * p.stride - p.pad_t <= iy; ++oy)
+            for (int ox = ox_lo; ox < p.Wo && ox * p.stride - p.pad_l <= ix; ++ox) {
+                float best = -INFINITY;
+                int by = -1, bx = -1;
+                for (int ky = 0; ky < p.k; ++ky) {
+                    const int y = oy * p.stride - p.pad_t + ky;
+                    if ((unsigned)y >= (unsigned)p.H) continue;
+                    for (int kx = 0; kx < p.k; ++kx) {
+                        const int xx = ox * p.stride - p.pad_l + kx;
+                        if ((unsigned)xx >= (unsigned)p.W) continue;
+                        const float v = xb[((long)y * p.W + xx) * p.C];
+                        if (v > best || by < 0) { best = v; by = y; bx = xx; }
+                    }
+                }
+                if (by == iy && bx == ix) acc += p.g[(((long)b * p.Ho + oy) * p.Wo + ox) * p.C + c];
+            }
+        p.dx[e] = p.accumulate ? p.dx[e] + acc : acc;
+    }
+}
+
+// y = x * r * gamma, r = rsqrt(max(sum_c x^2, 1e-12)).  One wave per pixel:
+//   dx = gamma*dy*r - x * r^3 * sum_c(gamma*dy*x)   (second term only while sum x^2 > 1e-12)
+//   tmp = dy * x * r  (column sums of tmp = d gamma)
+__global__ __launch_bounds__(256) void l2norm_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                        const float* __restrict__ gamma, const long pixels,
+                                                        const int C, float* __restrict__ dx, const int accumulate,
+                                                        float* __restrict__ tmp) {
+    const int lane = threadIdx.x & 63;
+    const long wave0 = ((long)blockIdx.x * 256 + threadIdx.x) >> 6;
+    const long nwaves = ((long)gridDim.x * 256) >> 6;
+    for (long px = wave0; px < pixels; px += nwaves) {
+        const float* xr = x + px * C;
+        const float* gr = dy + px * C;
+        float s = 0.f, t = 0.f;
+        for (int c = lane; c < C; c += 64) {
+            s += xr[c] * xr[c];
+            t += gamma[c] * gr[c] * xr[c];
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { s += __shfl_xor(s, o); t += __shfl_xor(t, o); }
+        const float r = 1.0f / sqrtf(fmaxf(s, 1e-12f));
+        const float k3 = s > 1e-12f ? r * r * r * t : 0.f;
+        for (int c = lane; c < C; c += 64) {
+            const float v = gamma[c] * gr[c] * r - xr[c] * k3;
+            dx[px * C + c] = accumulate ? dx[px * C + c] + v : v;
+            tmp[px * C + c] = gr[c] * xr[c] * r;
+        }
+    }
+}
+
+// g += coef * w   (Keras l2 kernel regulariser: d(l2 * sum w^2)/dw = 2 * l2 * w)
+__global__ __launch_bounds__(256) void axpy_kernel(float* __restrict__ g, const float* __restrict__ w, const long n,
+                                                  const float coef) {
+    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < n; e += (long)gridDim.x * 256) g[e] += coef * w[e];
+}
+
 // ------------------------------------------------------------------ Adam (TF training_ops.ApplyAdam form)
 // m += (g - m)(1 - b1); v += (g^2 - v)(1 - b2); var -= alpha * m / (sqrt(v) + eps),
 // alpha = lr * sqrt(1 - b2^t) / (1 - b1^t); g = grad * grad_scale (+ l2 * var where l2mask set)
@@ -515,7 +594,7 @@ static bool trainable(const std::string& name) {
 }
 
 // layers the training step executes: the un-fused layer list (fused kernels fold inference BatchNorm)
-static bool train_runs(const Layer& l) { return l.kind == LK_CONV || l.kind == LK_DW; }
+static bool train_runs(const Layer& l) { return l.kind == LK_CONV || l.kind == LK_DW || l.kind == LK_POOL || l.kind == LK_L2NORM; }
 
 static long chunks_for(long M, long unit_blocks, long* rows_per_chunk, long min_rows, long max_chunks) {
     long chunks = (2048 + unit_blocks - 1) / unit_blocks;          // ~8 workgroups per CU in total
@@ -657,9 +736,6 @@ long ssd_net_trainable_offset(const ssd_net* net, const char* name) {
 
 int ssd_net_train_begin(ssd_net* net, int batch) {
     SSD_CHECK_ARG(net && batch >= 1, "ssd_net_train_begin: bad arguments");
-    SSD_UNSUPPORTED_IF(net->backbone != SSD_MOBILENET_V2,
-                       "ssd_net_train_begin: the training step is built for the MobileNetV2 graph (BASELINE configs[3]); "
-                       "VGG16 needs max-pool / L2-normalisation backward");
     for (const auto& p : net->params)
         if (!p.set) {
             set_error("ssd_net_train_begin: parameter '%s' was never set", p.name.c_str());
@@ -716,6 +792,12 @@ int ssd_net_train_begin(ssd_net* net, int batch) {
         t.active = true;
         const size_t mc = (size_t)batch * l.Ho * l.Wo * l.Cout;
         maxC = std::max(maxC, l.Cout);
+        if (l.kind == LK_POOL) continue;
+        if (l.kind == LK_L2NORM) {
+            t.g_gamma = s->poff[l.p_gamma];
+            max_out = std::max(max_out, mc);
+            continue;
+        }
         t.g_kernel = s->poff[l.p_kernel];
         if (l.p_bias >= 0) t.g_bias = s->poff[l.p_bias];
         if (l.p_kernel2 >= 0) { t.g_kernel2 = s->poff[l.p_kernel2]; t.g_bias2 = s->poff[l.p_bias2]; }
@@ -801,6 +883,16 @@ int ssd_net_train_forward_backward(ssd_net* net, const float* image_dev, int B, 
         if (!t.active) continue;
         const long M = (long)B * l.Ho * l.Wo;
         const float* x = s.act[l.in];
+        if (l.kind == LK_POOL) {
+            rc = launch_maxpool(x, B, l.H, l.W, l.Cin, l.kh, l.stride, l.pt, l.pl, l.Ho, l.Wo, s.act[l.out], st);
+            if (rc) return rc;
+            continue;
+        }
+        if (l.kind == LK_L2NORM) {
+            rc = launch_l2norm(x, M, l.Cin, net->params[l.p_gamma].dev, s.act[l.out], st);
+            if (rc) return rc;
+            continue;
+        }
         if (l.kind == LK_CONV) {
             const int K = l.kh * l.kw * l.Cin;
             // re-pack the (just updated) weights: forward and backward-data forms
@@ -890,6 +982,35 @@ int ssd_net_train_forward_backward(ssd_net* net, const float* image_dev, int B, 
         if (!t.active) continue;
         const long M = (long)B * l.Ho * l.Wo;
         const float* x = s.act[l.in];
+        if (l.kind == LK_POOL || l.kind == LK_L2NORM) {
+            if (!s.gwritten[l.out]) {
+                set_error("train: no gradient reached tensor '%s'", net->tensors[l.out].name.c_str());
+                return SSD_E_STATE;
+            }
+            if (l.kind == LK_POOL) {
+                PoolBwdParams pp{};
+                pp.x = x; pp.g = s.gact[l.out]; pp.dx = s.gact[l.in];
+                pp.B = B; pp.H = l.H; pp.W = l.W; pp.C = l.Cin; pp.Ho = l.Ho; pp.Wo = l.Wo;
+                pp.k = l.kh; pp.stride = l.stride; pp.pad_t = l.pt; pp.pad_l = l.pl;
+                pp.accumulate = s.gwritten[l.in];
+                hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(grid_for((long)B * l.H * l.W * l.Cin)), dim3(256), 0, st, pp);
+                SSD_LAUNCH_CHECK();
+            } else {
+                const long blocks = (M + 3) / 4;
+                hipLaunchKernelGGL(l2norm_bwd_kernel, dim3((unsigned)(blocks < 8192 ? blocks : 8192)), dim3(256), 0, st, x,
+                                   s.gact[l.out], net->params[l.p_gamma].dev, M, l.Cin, s.gact[l.in], (int)s.gwritten[l.in],
+                                   s.scratch_dy);
+                SSD_LAUNCH_CHECK();
+                RedParams rp{};
+                rp.a = s.scratch_dy; rp.M = M; rp.C = l.Cin; rp.lda = l.Cin;
+                long chunks = 0;
+                rc = col_reduce<RED_SUM>(s, rp, &chunks, st);
+                if (!rc) rc = col_finalize(s, chunks, l.Cin, 1.0f, grads_flat_dev + t.g_gamma, nullptr, 0, st);
+                if (rc) return rc;
+            }
+            s.gwritten[l.in] = 1;
+            continue;
+        }
         const float* dY = nullptr;       // gradient w.r.t. the conv / depthwise output, dense [M][ldy]
         int ldy = l.Cout;
         if (l.head_kind) {
@@ -1014,6 +1135,17 @@ int ssd_net_train_forward_backward(ssd_net* net, const float* image_dev, int B, 
         if (rc) return rc;
         s.gwritten[l.in] = 1;
     }
+    // VGG16: kernel_regularizer=l2(5e-4) on every backbone / extra conv (models/ssd_vgg16.py:44-45;
+    // the head convs of models/header.py have none): d(5e-4 * sum w^2)/dw = 1e-3 * w
+    if (net->backbone == SSD_VGG16)
+        for (size_t i = 0; i < net->layers.size(); ++i) {
+            const Layer& l = net->layers[i];
+            if (l.kind != LK_CONV || l.head_kind || !s.tl[i].active) continue;
+            const Param& w = net->params[l.p_kernel];
+            hipLaunchKernelGGL(axpy_kernel, dim3(grid_for((long)w.count)), dim3(256), 0, st, grads_flat_dev + s.tl[i].g_kernel,
+                               w.dev, (long)w.count, 2.0f * 5e-4f);
+            SSD_LAUNCH_CHECK();
+        }
     return SSD_OK;
 }
 

@@ -143,7 +143,9 @@ class SSDModel(object):
                 # the table is only valid for this library build, this device and this anchor
                 # configuration (head widths follow len(aspect_ratios))
                 ars = "-".join(str(len(a)) for a in self.hyper_params["aspect_ratios"])
-                dev = torch.cuda.get_device_name(torch.cuda.current_device()).replace(" ", "_")
+                # (the marketing name is not stable -- it reads "" under rocprofv3 -- the ISA name is)
+                props = torch.cuda.get_device_properties(torch.cuda.current_device())
+                dev = "%s_cu%d" % (str(getattr(props, "gcnArchName", "gpu")).split(":")[0], props.multi_processor_count)
                 ver = lib.ssd_version().decode().replace(" ", "_").replace("/", "_")
                 path = os.path.join(cache, "%s_%d_%d_a%s_b%d_%s_%s.tune" % (
                     self.backbone, self.img_size, self.total_labels, ars, want, dev, ver))
