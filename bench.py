@@ -160,9 +160,14 @@ def main():
     tpath = os.path.join(REPO, "profiles", "traffic_%s_b%d.json" % (args.backbone, B))
     if os.path.exists(tpath) and hp["img_size"] == 300:
         try:
-            fam = json.load(open(tpath))["families"]["conv_mfma_kernel"]
-            fetch = 2.0 * fam["FETCH_SIZE"]["KB_per_launch_reported"] * 1024.0      # gfx950: x2 for wide reads
-            write = fam["WRITE_SIZE"]["KB_per_launch_reported"] * 1024.0
+            fams = json.load(open(tpath))["families"]
+            fam_names = [k for k in ("conv_mfma_kernel", "conv_wino_kernel") if k in fams]
+            nl = sum(fams[k]["FETCH_SIZE"]["launches"] for k in fam_names)
+            # launch-weighted mean over the family's kernels (implicit-GEMM + Winograd tiles)
+            fetch = 2.0 * 1024.0 * sum(fams[k]["FETCH_SIZE"]["KB_per_launch_reported"] * fams[k]["FETCH_SIZE"]["launches"]
+                                       for k in fam_names) / nl      # gfx950: x2 for wide reads
+            write = 1024.0 * sum(fams[k]["WRITE_SIZE"]["KB_per_launch_reported"] * fams[k]["WRITE_SIZE"]["launches"]
+                                 for k in fam_names) / sum(fams[k]["WRITE_SIZE"]["launches"] for k in fam_names)
             traffic = fetch + write
             tj = json.load(open(tpath))
             traffic_detail = {"fetch_bytes_per_launch_x2_corrected": fetch, "write_bytes_per_launch": write,

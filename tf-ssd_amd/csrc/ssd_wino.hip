@@ -64,7 +64,11 @@ __global__ __launch_bounds__(256) void wino_pack_kernel(const float* __restrict_
 
 template <int NT, int WT, int WN>
 __global__ __launch_bounds__(256, (NT <= 4 ? 2 : 1)) void conv_wino_kernel(const ConvParams p) {
-    constexpr int TT = 16 * WT, TN = 16 * NT * WN, LDK = 24;      // 24-float rows: conflict-free b128 fragments
+    // LDS rows are UNPADDED 16-float slabs with the 16-byte quad index XOR-ed by (row >> 1) & 3: under
+    // gfx950's b128 lane grouping this is conflict-free for the fragment reads AND the tile writes
+    // (brute-forced over the four lane groups; padded 24-float rows were 2-way conflicted on the writes:
+    // SQ_LDS_BANK_CONFLICT 5 % of the wave cycles) and takes a third less LDS
+    constexpr int TT = 16 * WT, TN = 16 * NT * WN, LDK = 16;
     constexpr int XI = TT * 4, XP = (XI + 255) / 256;             // input items (tile, channel quad)
     constexpr int WU = 4 * TN * 4, WP = (WU + 255) / 256;         // U units: 4 b x TN rows x 4 quads
     static_assert(WT * WN == 4, "4 waves per block");
@@ -130,7 +134,7 @@ __global__ __launch_bounds__(256, (NT <= 4 ? 2 : 1)) void conv_wino_kernel(const
 #pragma unroll
             for (int ni = 0; ni < NT; ++ni) Y[dy][dx][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    const int frow = lane & 15, fk = (lane >> 4) * 4;
+    const int frow = lane & 15, fk = ((lane >> 4) ^ ((frow >> 1) & 3)) << 2;      // swizzled fragment quad (tile rows are multiples of 16)
     const long rowstep = (long)p.W * p.Cin;
 
 #pragma unroll 1
@@ -170,7 +174,7 @@ __global__ __launch_bounds__(256, (NT <= 4 ? 2 : 1)) void conv_wino_kernel(const
             for (int ps = 0; ps < XP; ++ps) {
                 const int it = tid + ps * 256;
                 if (XI % 256 != 0 && it >= XI) continue;
-                float* dst = Vs + (it >> 2) * LDK + (it & 3) * 4;
+                float* dst = Vs + (it >> 2) * LDK + (((it & 3) ^ ((it >> 3) & 3)) << 2);      // row = it >> 2: key (row >> 1) & 3
                 f32x4 c[4];
 #pragma unroll
                 for (int cc = 0; cc < 4; ++cc) c[cc] = x1[ps][cc] + sgn * x2[ps][cc];
@@ -185,7 +189,7 @@ __global__ __launch_bounds__(256, (NT <= 4 ? 2 : 1)) void conv_wino_kernel(const
                 const int u = tid + ps * 256;
                 if (WU % 256 != 0 && u >= WU) continue;
                 const int bsel = u / (TN * 4), rem = u - bsel * (TN * 4);
-                *reinterpret_cast<f32x4*>(Us + (bsel * TN + (rem >> 2)) * LDK + (rem & 3) * 4) = wr[ps];
+                *reinterpret_cast<f32x4*>(Us + (bsel * TN + (rem >> 2)) * LDK + (((rem & 3) ^ ((rem >> 3) & 3)) << 2)) = wr[ps];
             }
         };
 
