@@ -139,7 +139,11 @@ def main():
     for r in info:
         if r["flops"] == 0 and r["bytes"] == 0 and r["kind"] != "nms":
             continue                      # layer replaced by a fused kernel (only event overhead)
-        k = r["kind"] if not (r["kind"] == "conv" and not r["config"].startswith("mfma_")) else "conv_direct"
+        k = r["kind"]
+        if k == "conv" and r["config"].startswith("wino_"):
+            k = "conv_winograd"
+        elif k == "conv" and not r["config"].startswith("mfma_"):
+            k = "conv_direct"
         kinds[k] = kinds.get(k, 0.0) + r["ms"]
     achieved = mfma_flops / (mfma_ms * 1e-3) / 1e12 if mfma_ms > 0 else 0.0
     fused = [r for r in info if r["kind"] == "fused" and r["flops"] > 0]
@@ -282,15 +286,16 @@ def train_bench(args, hp, get_model, rank, world, dist):
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     last = float((loc + conf).mean().item())
-    fwd_gflop = 2.026 * B                      # conv MACs x 2 per image (forward)
+    fwd_gflop = (2.026 if args.backbone == "mobilenet_v2" else 62.747) * B     # conv MACs x 2 per image (forward)
     step_tflops = 3.0 * fwd_gflop * 1e9 / (elapsed / args.steps) / 1e12      # forward + backward-data + backward-weights
     result = {
-        "metric": "images/sec SSD300 (MobileNetV2) training step", "value": world * B * args.steps / elapsed,
+        "metric": "images/sec SSD300 (%s) training step" % ("MobileNetV2" if args.backbone == "mobilenet_v2" else "VGG16"),
+        "value": world * B * args.steps / elapsed,
         "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic (seeded images + ground truth, Keras-default initial weights)",
-        "config": {"workload": "SSD300 mobilenet_v2 training, batch=%d per GPU, fp32, target assignment + fwd + loss + bwd + "
-                               "grad all-reduce + Adam (BASELINE.json configs[3] shape; fp32 instead of bf16)" % B,
+        "config": {"workload": "SSD300 %s training, batch=%d per GPU, fp32, target assignment + fwd + loss + bwd + "
+                               "grad all-reduce + Adam (BASELINE.json configs[3] shape; fp32 instead of bf16)" % (args.backbone, B),
                    "global_batch": world * B, "parallelism": "batch-DP x%d, RCCL all-reduce of %d fp32 gradients" % (
                        world, ssd_hip.lib().ssd_net_trainable_floats(model._net)),
                    "loss_first_step": first, "loss_last_step": last},

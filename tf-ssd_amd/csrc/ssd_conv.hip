@@ -11,8 +11,10 @@
 //   * Both operands are K-contiguous (NHWC activations; weights pre-packed [N][K]), so a
 //     lane fetches 4 consecutive k with one ds_read_b128 and feeds 4 MFMA k-steps from it
 //     (the MFMA k index is a summation index: any bijection shared by A and B is valid).
-//   * 256-thread blocks = 4 waves (WM x WN), wave tile (16*MT) x (16*NT); LDS tiles
-//     [rows][BK+4] (16-byte padded rows); global->register prefetch of the next K tile is in
+//   * 256-thread blocks = 4 waves (WM x WN), wave tile (16*MT) x (16*NT); LDS tiles are
+//     UNPADDED [rows][BK] with the 16-byte column index XOR-swizzled by the row (BK >= 32;
+//     conflict-free fragment reads and tile writes under gfx950's b128 lane grouping) or
+//     [rows][BK+4] for BK = 16; two LDS stages, global->register prefetch of the next K tile in
 //     flight while the current one is multiplied.
 //   * im2col is never materialised: for k x k convs the per-row (b, iy0, ix0) is decoded
 //     once per block and each K tile (BK | Cin) lies inside one filter tap; TF's asymmetric
