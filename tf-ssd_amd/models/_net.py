@@ -152,8 +152,14 @@ class SSDModel(object):
                 if os.path.exists(path):
                     with open(path, "rb") as f:
                         _h.check(lib.ssd_net_set_tuning(self._net, f.read()), "ssd_net_set_tuning")
+            # a re-finalize of the same shapes (new weights: training, load_weights) reuses the
+            # table the first finalize tuned instead of timing every candidate again
+            memo = getattr(self, "_tuning_memo", None)
+            if memo and memo[0] == want and not (path and os.path.exists(path)):
+                _h.check(lib.ssd_net_set_tuning(self._net, memo[1].encode()), "ssd_net_set_tuning")
             _h.check(lib.ssd_net_finalize(self._net, want), "ssd_net_finalize")
             self._finalized_for = want
+            self._tuning_memo = (want, self.get_tuning())
             if path and not os.path.exists(path):
                 # one process per GPU may race on the same file: write privately, publish atomically
                 os.makedirs(cache, exist_ok=True)
