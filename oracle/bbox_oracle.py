@@ -151,8 +151,12 @@ def calculate_actual_outputs(prior_boxes, gt_boxes, gt_labels, hyper_params, ret
     gt_boxes = np.asarray(gt_boxes, F32)
     gt_labels = np.asarray(gt_labels, np.int32)
     iou_map = generate_iou_map(prior_boxes, gt_boxes)                     # [B,N,G]
-    max_idx = np.argmax(iou_map, axis=2).astype(np.int32)                 # first max wins
-    merged = np.max(iou_map, axis=2)
+    # [3P] tf.argmax / tf.reduce_max are Eigen reducers: the accumulator starts at lowest() and is
+    # replaced only by a strictly greater value -> first max wins and a NaN IoU (0/0: degenerate
+    # prior against a padded ground-truth box) is never selected (NumPy's argmax would pick it)
+    safe = np.where(np.isnan(iou_map), F32(-np.inf), iou_map)
+    max_idx = np.argmax(safe, axis=2).astype(np.int32)                    # first max wins (:113)
+    merged = np.max(safe, axis=2)                                         # (:115)
     pos = merged > iou_threshold
     gt_map = np.take_along_axis(gt_boxes, max_idx[..., None], axis=1)     # [B,N,4]
     exp_gt = np.where(pos[..., None], gt_map, F32(0))

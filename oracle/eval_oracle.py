@@ -36,17 +36,16 @@ def update_stats(pred_bboxes, pred_labels, pred_scores, gt_boxes, gt_labels, sta
     max_idx = np.empty((B, T), np.int32)                        # :22 argmax over G (first max)
     for b in range(B):
         for t in range(T):
-            best, arg = iou_map[b, t, 0], 0
-            for g in range(1, G):
-                if iou_map[b, t, g] > best or (np.isnan(iou_map[b, t, g]) and not np.isnan(best)):
+            best, arg = np.float32(-np.inf), 0      # [3P] Eigen reducers: start at lowest(), strict >: NaN never wins
+            for g in range(G):
+                if iou_map[b, t, g] > best:
                     best, arg = iou_map[b, t, g], g
             merged[b, t], max_idx[b, t] = best, arg
-    # :23 argsort DESCENDING, equal keys by ascending index; NaN keys last
+    # :23 argsort DESCENDING, equal keys by ascending index
     sorted_ids = np.empty((B, T), np.int64)
     for b in range(B):
-        keys = [(1 if np.isnan(merged[b, t]) else 0, -float(0.0 if np.isnan(merged[b, t]) else merged[b, t]), t)
-                for t in range(T)]
-        sorted_ids[b] = [k[2] for k in sorted(keys)]
+        keys = [(-float(merged[b, t]), t) for t in range(T)]
+        sorted_ids[b] = [k[1] for k in sorted(keys)]
     # :25-30 unique_with_counts over all gt labels; -1 is padding
     flat = np.asarray(gt_labels).reshape(-1)
     for lab in np.unique(flat):

@@ -167,8 +167,10 @@ void oracle_match_encode(const float *priors, const float *gt, const int *gt_lab
         for (int i = 0; i < N; ++i) {
             const float *p = priors + 4 * i;
             int am = 0;
-            float best = G > 0 ? pair_iou(p, gt + (size_t)b * G * 4) : 0.0f;
-            for (int g = 1; g < G; ++g) {
+            /* [3P] Eigen arg-max / max reducers: start at lowest(), strictly-greater replaces: first
+             * max wins, a NaN IoU (0/0) is never selected */
+            float best = G > 0 ? -3.402823466e38f : 0.0f;
+            for (int g = 0; g < G; ++g) {
                 float v = pair_iou(p, gt + ((size_t)b * G + g) * 4);
                 if (v > best) { best = v; am = g; }
             }

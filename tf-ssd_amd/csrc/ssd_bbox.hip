@@ -434,11 +434,14 @@ __global__ __launch_bounds__(256) void match_encode_kernel(
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= N) return;
     const float4 p = priors[i];
+    // [3P] tf.argmax / reduce_max (Eigen reducers: accumulator starts at lowest(), replaced only
+    // by a strictly greater value): first max wins and a NaN IoU (0/0: degenerate prior against a
+    // padded ground-truth box) is never selected
     int am = 0;
-    float best = G > 0 ? pair_iou(p, s_gt[0]) : 0.0f;
-    for (int g = 1; g < G; ++g) {
+    float best = G > 0 ? -3.402823466e38f : 0.0f;
+    for (int g = 0; g < G; ++g) {
         const float v = pair_iou(p, s_gt[g]);
-        if (v > best) { best = v; am = g; }       // first max wins (tf.argmax)
+        if (v > best) { best = v; am = g; }
     }
     const bool pos = best > iou_thr;              // strict (utils/train_utils.py:117)
     float4 gb = make_float4(0.f, 0.f, 0.f, 0.f);

@@ -34,6 +34,8 @@ def update_stats(pred_bboxes, pred_labels, pred_scores, gt_boxes, gt_labels, sta
     for cid, n in zip(*np.unique(gt_label.ravel(), return_counts=True)):
         if cid != -1:
             stats[int(cid)]["total"] += int(n)
+    # [3P] Eigen max / arg-max reducers never select a NaN (0/0 IoU of a degenerate box against padding)
+    iou = np.where(np.isnan(iou), -np.inf, iou)
     best_iou, best_gt = iou.max(axis=2), iou.argmax(axis=2)
     visit = np.argsort(-best_iou, axis=1, kind="stable")
     for img in range(best_iou.shape[0]):
