@@ -922,7 +922,48 @@ static int forward_impl(ssd_net* net, const float* image_dev, int B, float* delt
             }
         return SSD_OK;
     };
-    for (size_t i = 0; i < net->layers.size(); ++i) {
+    // Issue order (matters under hipGraph replay: the executor starts ready nodes in capture order).
+    // Every kernel of the heavy part of the graph fills the whole GPU, so overlapping two of them only
+    // splits the machine (measured: head 1 beside block_13's depthwise+project -> 239 + 212 us instead
+    // of 187 + 37).  What CAN hide is the latency-bound tail (extras 2-4, heads 3-6: ~150 us of 5-20 us
+    // kernels): the two big head convs (side stream 1) are therefore issued when the first small head
+    // (side stream 2) is, i.e. behind the last heavy main-chain layer, and run beside that tail; the
+    // small heads are issued right behind their producers.
+    std::vector<size_t> order;
+    order.reserve(net->layers.size());
+    if (overlap) {
+        std::vector<char> placed(net->layers.size(), 0);
+        std::vector<size_t> pending_big;
+        auto place_consumers = [&](int out_tensor) {
+            for (size_t j = 0; j < net->layers.size(); ++j) {
+                const Layer& c = net->layers[j];
+                if (placed[j] || !c.side || c.in != out_tensor || !layer_runs(*net, c)) continue;
+                placed[j] = 1;
+                if (c.side == 1) { pending_big.push_back(j); continue; }
+                for (size_t b : pending_big) order.push_back(b);
+                pending_big.clear();
+                order.push_back(j);
+            }
+        };
+        for (size_t i = 0; i < net->layers.size(); ++i) {
+            if (placed[i]) continue;
+            const Layer& l = net->layers[i];
+            if (l.side && layer_runs(*net, l)) continue;  // placed behind its producer
+            if (l.kind == LK_SOFTMAX) continue;           // the join point goes last
+            order.push_back(i);
+            placed[i] = 1;
+            if (l.out > 0 && layer_runs(*net, l)) place_consumers(l.out);
+        }
+        for (size_t b : pending_big) order.push_back(b);
+        for (size_t i = 0; i < net->layers.size(); ++i)
+            if (!placed[i] && net->layers[i].kind != LK_SOFTMAX) { order.push_back(i); placed[i] = 1; }
+        for (size_t i = 0; i < net->layers.size(); ++i)
+            if (!placed[i]) order.push_back(i);
+    } else {
+        for (size_t i = 0; i < net->layers.size(); ++i) order.push_back(i);
+    }
+    for (size_t oi = 0; oi < order.size(); ++oi) {
+        const size_t i = order[oi];
         Layer& l = net->layers[i];
         if (layer_runs(*net, l)) {
             if (overlap && l.side) {
