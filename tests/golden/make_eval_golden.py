@@ -1,32 +1,30 @@
 """Generates tests/golden/eval_map.npz by EXECUTING the reference's own pure-NumPy functions
 ``init_stats`` / ``calculate_ap`` / ``calculate_mAP`` (/root/reference/utils/eval_utils.py:5-17,
-56-85) in the build container.  The module's first line is ``import tensorflow as tf`` and
-TensorFlow is not installable here, so an EMPTY placeholder module named ``tensorflow`` is put in
-sys.modules only to let the import statement succeed; the three functions called below never
-touch it (``update_stats``, which does, is NOT called -- it is restated in oracle/eval_oracle.py).
-Run from the repo root:  python tests/golden/make_eval_golden.py
+56-85) in the build container.  The module itself cannot be imported (its first line is
+``import tensorflow as tf`` and TensorFlow is not installable here), so the three function
+definitions -- which reference nothing but ``np`` -- are taken from the parsed file (``ast``) and
+compiled on their own; ``update_stats``, which does use TF ops, is NOT executed: it is restated in
+oracle/eval_oracle.py.  Run from the repo root:  python tests/golden/make_eval_golden.py
 Only data (inputs + expected outputs) is written; no reference source travels."""
+import ast
 import os
-import sys
 import types
 
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 REF = "/root/reference"
+WANTED = ("init_stats", "calculate_ap", "calculate_mAP")
 
 
 def load_reference_eval_utils():
-    sys.modules.setdefault("tensorflow", types.ModuleType("tensorflow"))     # import placeholder only
-    pkg = types.ModuleType("utils")
-    pkg.__path__ = []                                                        # `from utils import bbox_utils`
-    sys.modules["utils"] = pkg
-    sys.modules["utils.bbox_utils"] = types.ModuleType("utils.bbox_utils")
-    pkg.bbox_utils = sys.modules["utils.bbox_utils"]
-    import importlib.util
-    spec = importlib.util.spec_from_file_location("ref_eval_utils", os.path.join(REF, "utils", "eval_utils.py"))
-    mod = importlib.util.module_from_spec(spec)
-    spec.loader.exec_module(mod)
+    path = os.path.join(REF, "utils", "eval_utils.py")
+    tree = ast.parse(open(path).read(), path)
+    defs = [n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name in WANTED]
+    assert sorted(d.name for d in defs) == sorted(WANTED)
+    mod = types.ModuleType("ref_eval_utils")
+    mod.np = np
+    exec(compile(ast.Module(body=defs, type_ignores=[]), path, "exec"), mod.__dict__)
     return mod
 
 
