@@ -199,3 +199,47 @@ def test_u1_box_helpers_product_vs_oracle():
     # exact .5 products round to even in both directions
     half = np.array([[0.5, 1.5, 2.5, 3.5]], np.float32)
     np.testing.assert_array_equal(bu.denormalize_bboxes(half, 1, 1).numpy(), [[0, 2, 2, 4]])
+
+
+def test_new_entry_points_validate_without_a_device():
+    """Argument / state checks of the round-2 entry points run before any device access: they can
+    be exercised on a CPU-only host (status codes + ssd_last_error, nothing thrown across the ABI)."""
+    import ssd_hip
+    l = ssd_hip.lib()
+    vp = ctypes.c_void_p
+    one = vp(16)            # a non-NULL, 16-byte aligned dummy (never dereferenced: the checks fail first)
+    # ssd_loss: sizes, missing pairs, workspace
+    assert l.ssd_loss(one, one, one, one, 1, 0, 21, 3.0, 1.0, None, None, None, None, None, None, 1.0, one, 1 << 20, None) == -1
+    assert b"bad sizes" in l.ssd_last_error()
+    assert l.ssd_loss(None, None, None, None, 1, 8, 21, 3.0, 1.0, None, None, None, None, None, None, 1.0, one, 1 << 20, None) == -1
+    assert l.ssd_loss(one, None, None, None, 1, 8, 21, 3.0, 1.0, None, None, None, None, None, None, 1.0, one, 1 << 20, None) == -1
+    assert l.ssd_loss(one, one, None, None, 1, 8, 21, 3.0, 1.0, None, None, None, None, one, one, 1.0, one, 1 << 20, None) == -1
+    assert b"grad_logits" in l.ssd_last_error()
+    assert l.ssd_loss(one, one, one, one, 4, 2268, 21, 3.0, 1.0, None, None, None, None, None, None, 1.0, one, 16, None) == -1
+    assert b"workspace" in l.ssd_last_error()
+    assert l.ssd_loss_workspace_bytes(32, 2268) >= 32 * 2268 * 9 and l.ssd_loss_workspace_bytes(-1, 5) == 0
+    assert l.ssd_loss(one, one, one, one, 0, 8, 21, 3.0, 1.0, None, None, None, None, None, None, 1.0, None, 0, None) == 0   # empty batch
+    # ssd_preprocess
+    assert l.ssd_preprocess(one, 1, 0, 5, 3, 300, 300, one, None) == -1
+    assert l.ssd_preprocess(None, 1, 5, 5, 3, 300, 300, one, None) == -1
+    assert l.ssd_preprocess(None, 0, 5, 5, 3, 300, 300, None, None) == 0
+    # Winograd op: weight size query, not-applicable geometry
+    assert l.ssd_conv_wino_weight_floats(576, 100) == 16 * 112 * 576 and l.ssd_conv_wino_num_configs() >= 4
+    d = ssd_hip.ConvDesc(1, 8, 8, 16, 16, 3, 3, 2, 1, 1, 1, 1, 1, 0, 0)
+    assert l.ssd_conv2d_wino(ctypes.byref(d), one, one, None, None, one, 0, 0, 0, 1, None, None) == -3
+    d = ssd_hip.ConvDesc(1, 8, 8, 16, 16, 3, 3, 1, 1, 1, 1, 1, 1, 0, 1)
+    assert l.ssd_conv2d_wino(ctypes.byref(d), one, one, None, None, one, 0, 0, 0, 1, None, None) == -1       # residual
+    # training entry points: state machine
+    na = (ctypes.c_int * 6)(3, 5, 5, 5, 3, 3)
+    net = l.ssd_net_create(ssd_hip.MOBILENET_V2, 300, 6, na, 21)
+    assert l.ssd_net_trainable_floats(net) == 8493678                  # 8.53 M parameters minus the moving statistics
+    assert l.ssd_net_trainable_offset(net, b"Conv1/kernel") == 0
+    assert l.ssd_net_trainable_offset(net, b"bn_Conv1/moving_mean") == -1
+    assert l.ssd_net_trainable_offset(net, b"bn_Conv1/gamma") == 864
+    assert l.ssd_net_train_forward_backward(net, one, 1, one, one, 3.0, 1.0, one, None, None, None) == -4
+    assert b"train_begin" in l.ssd_last_error()
+    assert l.ssd_net_adam_step(net, one, 1e-3, 0.9, 0.999, 1e-7, 1.0, None) == -4
+    assert l.ssd_net_train_begin(net, 0) == -1
+    assert l.ssd_net_train_begin(net, 4) == -4 and b"never set" in l.ssd_last_error()
+    assert l.ssd_net_train_steps(net) == 0 and l.ssd_net_train_fetch(net, b"probs", 1, None, 0) < 0
+    l.ssd_net_destroy(net)
