@@ -6,6 +6,7 @@ OUT=../libssd_hip.so
 HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
 COMMON="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function"
 mkdir -p build
+rm -f build/.failed
 need_link=0
 compile() {  # src extra-flags
   local src=$1; shift
@@ -13,7 +14,8 @@ compile() {  # src extra-flags
   if [ "$FORCE" = 1 ] || [ ! -f "$obj" ] || [ "$src" -nt "$obj" ] || [ common.h -nt "$obj" ] \
      || [ ../../include/ssd_hip.h -nt "$obj" ] || [ ssd_conv.h -nt "$obj" ] || [ ssd_net.h -nt "$obj" ] || { [ -f "${src%.*}.h" ] && [ "${src%.*}.h" -nt "$obj" ]; }; then
     echo "hipcc $src"
-    $HIPCC $COMMON "$@" -c "$src" -o "$obj"
+    # translation units compile in parallel (ssd_conv.hip alone instantiates ~80 kernels)
+    ( $HIPCC $COMMON "$@" -c "$src" -o "$obj.tmp" && mv "$obj.tmp" "$obj" ) || touch build/.failed &
     need_link=1
   fi
 }
@@ -27,6 +29,8 @@ compile ssd_data.hip -ffp-contract=off -fhip-fp32-correctly-rounded-divide-sqrt
 for s in ssd_conv.hip ssd_wino.hip ssd_ops.hip ssd_fused.hip ssd_dwproj.hip ssd_net.hip ssd_train.hip; do
   [ -f "$s" ] && compile "$s"
 done
+wait
+if [ -f build/.failed ]; then rm -f build/.failed; echo "compilation failed" >&2; exit 1; fi
 if [ $need_link = 1 ] || [ ! -f $OUT ]; then
   echo "link $OUT"
   $HIPCC --offload-arch=gfx950 -shared -fPIC -o $OUT build/*.o
