@@ -280,3 +280,9 @@ def test_trainer_entry_point_fit(tmp_path, monkeypatch, capsys):
     from utils import h5_reader
     w = h5_reader.load_keras_weights(path)
     assert "bn_Conv1/moving_mean" in w and w["Conv1/kernel"].shape == (3, 3, 3, 32)
+    # the predictor entry point picks the trained checkpoint up (reference predictor.py:45-46)
+    monkeypatch.setenv("SSD_SYNTHETIC_ITEMS", "8")
+    predictor = importlib.import_module("predictor")
+    b, l, s = predictor.main(["--backbone", "mobilenet_v2"])
+    out = capsys.readouterr().out
+    assert "no trained weights" not in out and b.shape == (8, 200, 4) and np.isfinite(s).all()
