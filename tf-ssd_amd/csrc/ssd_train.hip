@@ -753,25 +753,14 @@ int ssd_net_train_begin(ssd_net* net, int batch) {
     if (!rc) rc = talloc(*s, s->P, &s->m);
     if (!rc) rc = talloc(*s, s->P, &s->v);
     if (rc) { ssd_train_state_free(s); return rc; }
-    if (old) {
-        SSD_HIP(hipMemcpy(s->m, old->m, s->P * sizeof(float), hipMemcpyDeviceToDevice));
-        SSD_HIP(hipMemcpy(s->v, old->v, s->P * sizeof(float), hipMemcpyDeviceToDevice));
-        s->step = old->step;
-    } else {
-        SSD_HIP(hipMemset(s->m, 0, s->P * sizeof(float)));
-        SSD_HIP(hipMemset(s->v, 0, s->P * sizeof(float)));
-    }
     s->poff.assign(net->params.size(), -1);
-    long off = 0;
-    for (size_t i = 0; i < net->params.size(); ++i) {
-        Param& p = net->params[i];
-        if (!trainable(p.name)) continue;
-        s->poff[i] = off;
-        SSD_HIP(hipMemcpy(s->flat + off, p.dev, p.count * sizeof(float), hipMemcpyDeviceToDevice));
-        if (!p.in_flat) (void)hipFree(p.dev);
-        p.dev = s->flat + off;
-        p.in_flat = true;
-        off += (long)p.count;
+    {
+        long off = 0;
+        for (size_t i = 0; i < net->params.size(); ++i) {
+            if (!trainable(net->params[i].name)) continue;
+            s->poff[i] = off;
+            off += (long)net->params[i].count;
+        }
     }
     // ---- activations, activation gradients
     s->act.assign(net->tensors.size(), nullptr);
@@ -847,11 +836,40 @@ int ssd_net_train_begin(ssd_net* net, int batch) {
             rc = SSD_E_HIP;
         }
     }
-    if (rc) {
-        // parameters already live in the new flat vector: keep the state so they stay valid
-        net->train = s;
-        if (old) { old->flat = nullptr; }
+    if (rc) {                           // nothing of the net was touched yet: the previous state (if any) stays valid
+        ssd_train_state_free(s);
         return rc;
+    }
+    // ---- every allocation succeeded: adopt the optimiser state and move the parameters
+    bool copy_failed = false;
+    if (old) {
+        copy_failed |= hipMemcpy(s->m, old->m, s->P * sizeof(float), hipMemcpyDeviceToDevice) != hipSuccess;
+        copy_failed |= hipMemcpy(s->v, old->v, s->P * sizeof(float), hipMemcpyDeviceToDevice) != hipSuccess;
+        s->step = old->step;
+    } else {
+        copy_failed |= hipMemset(s->m, 0, s->P * sizeof(float)) != hipSuccess;
+        copy_failed |= hipMemset(s->v, 0, s->P * sizeof(float)) != hipSuccess;
+    }
+    {
+        long off = 0;
+        for (size_t i = 0; i < net->params.size() && !copy_failed; ++i) {
+            if (s->poff[i] < 0) continue;
+            copy_failed |= hipMemcpy(s->flat + off, net->params[i].dev, net->params[i].count * sizeof(float),
+                                     hipMemcpyDeviceToDevice) != hipSuccess;
+            off += (long)net->params[i].count;
+        }
+    }
+    if (copy_failed) {
+        set_error("ssd_net_train_begin: device copy failed");
+        ssd_train_state_free(s);
+        return SSD_E_HIP;
+    }
+    for (size_t i = 0; i < net->params.size(); ++i) {
+        Param& p = net->params[i];
+        if (s->poff[i] < 0) continue;
+        if (!p.in_flat) (void)hipFree(p.dev);
+        p.dev = s->flat + s->poff[i];
+        p.in_flat = true;
     }
     if (old) ssd_train_state_free(old);
     net->train = s;
