@@ -222,7 +222,7 @@ def main():
                      "achieved_step": step_tflops, "frac_step": step_tflops / PEAK_FP32_MFMA_TFLOPS,
                      "algorithmic_gflop_per_step_all": step_flops / 1e9},
         # the other half of the step: whole-block / depthwise+project / stem kernels (MFMA + VALU depthwise)
-        "roofline_fused": {"bound": "mfma", "kernel": "mbv2_stem_kernel + mbv2_block_kernel + dwproj8_kernel (fused inverted-residual family)",
+        "roofline_fused": {"bound": "mfma", "kernel": "mbv2_stem_kernel + mbv2_block_kernel + mbv2_image_block_kernel + dwproj8_kernel (fused inverted-residual family)",
                            "achieved": fused_flops / (fused_ms * 1e-3) / 1e12 if fused_ms > 0 else None,
                            "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
                            "frac": (fused_flops / (fused_ms * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS) if fused_ms > 0 else None,

@@ -261,8 +261,8 @@ def test_mobilenet_v2_ssd_forward_parity(mbv2):
     d, p = m(x)
     d, p = _np(d), _np(p)
     assert any(l["kind"] == "fused" and l["flops"] > 0 for l in m.layers(2))
-    for name in ("expanded_conv_project_BN", "block_1_out", "block_2_out", "block_3_out", "block_5_out", "block_6_out", "block_12_out",
-                 "block_13_expand_relu", "out_relu", "extra4_2"):
+    for name in ("expanded_conv_project_BN", "block_1_out", "block_2_out", "block_3_out", "block_5_out", "block_6_out", "block_7_out",
+                 "block_9_out", "block_10_out", "block_12_out", "block_13_expand_relu", "block_14_out", "block_16_out", "out_relu", "extra4_2"):
         a = m.fetch_activation(name).reshape(acts[name].shape)
         _close(a, acts[name])
     assert d.shape == (2, 2268, 4) and p.shape == (2, 2268, 21)
@@ -495,6 +495,40 @@ def test_forward_parity_with_poisoned_arena(backbone, monkeypatch):
         assert np.isfinite(_np(p)).all() and np.isfinite(_np(d)).all()
         assert np.abs(_np(p) - rp).max() <= 1e-4
         _abs(_np(d), rd)
+
+
+@pytest.mark.parametrize("B", [1, 5, 24, 232])
+def test_image_block_kernel_vs_layer_kernels(B):
+    """Whole-image inverted-residual kernel (csrc/ssd_imgblock.hip; blocks 7-12, 14-16) against the
+    expand GEMM + depthwise/project kernels on the same weights: B = 1 / 5 take 12 channel groups per
+    image whose slabs cross XCDs (ticket + last-arriver combine), B = 24 takes 8-10 groups, B = 232
+    the direct one-group epilogue.  Run twice: bitwise repeatable (fixed group summation order)."""
+    from models.ssd_mobilenet_v2 import get_model
+    hp = helpers.hyper_params("mobilenet_v2")
+    w = helpers.synthetic_weights("mobilenet_v2", hp)
+    x = helpers.images(min(B, 8), 300, seed=17)
+    if B > 8:
+        x = np.concatenate([x] * ((B + 7) // 8))[:B] * np.linspace(0.5, 1.0, B, dtype=np.float32)[:, None, None, None]
+    m = get_model(hp, max_batch=B)
+    m.set_weights(w)
+    names = ["block_%d_out" % k for k in (7, 8, 9, 10, 11, 12, 14, 15, 16)]
+    m.set_option("fuse_image", 0)
+    d0, p0 = m(x)
+    ref = {n: m.fetch_activation(n).copy() for n in names}
+    assert not any(l["name"] == "block_7_fused" and l["flops"] > 0 for l in m.layers(B))
+    m.set_option("fuse_image", 2)       # 2: wherever the kernel applies (1 = where it won the finalize-time race)
+    d1, p1 = m(x)
+    assert any(l["name"] == "block_7_fused" and l["flops"] > 0 for l in m.layers(B))
+    got = {n: m.fetch_activation(n).copy() for n in names}
+    for n in names:
+        scale = np.abs(ref[n]).max()
+        assert np.abs(got[n] - ref[n]).max() <= 2e-5 * scale, n
+    assert np.abs(_np(p1) - _np(p0)).max() <= 2e-5
+    d2, p2 = m(x)
+    np.testing.assert_array_equal(_np(d2), _np(d1))
+    np.testing.assert_array_equal(_np(p2), _np(p1))
+    for n in names:
+        np.testing.assert_array_equal(m.fetch_activation(n), got[n])
 
 
 def test_get_head_from_outputs_composition():

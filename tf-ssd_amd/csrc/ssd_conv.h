@@ -46,6 +46,10 @@ struct FusedBlockParams {
     int B, H, W, Cin, Ce, Cout, Ho, Wo, stride, pad_t, pad_l;
     int kpad_e, kpad_p, npad_p;
     int tiles_y, tiles_x;       // filled by the launcher
+    // whole-image kernel (csrc/ssd_imgblock.hip): expanded-channel groups per image and their meeting point
+    int groups;                 // G >= 1 (filled by the caller from image_block_groups)
+    float* slabs;               // [G][B][Ho*Wo][Cout] partial sums (G > 1)
+    unsigned* tickets;          // [B] arrival counters, zero between launches
     long long* dbg;             // optional per-phase cycle counters [blocks][8] (profiling builds)
     int ablate;                 // diagnostics: 1 skip expand MFMAs, 2 skip depthwise math, 4 skip project MFMAs, 8 skip expand epilogue math
 };
@@ -84,6 +88,10 @@ bool stem_supported(const StemParams& p);
 int launch_stem(StemParams p, hipStream_t st);
 bool fused_block_supported(const FusedBlockParams& p);
 int launch_fused_block(FusedBlockParams p, hipStream_t st);
+bool image_block_supported(const FusedBlockParams& p);
+int image_block_groups(const FusedBlockParams& p, int B);
+size_t image_block_slab_floats(const FusedBlockParams& p, int B);
+int launch_image_block(FusedBlockParams p, hipStream_t st);
 
 inline int round_up(int v, int a) { return (v + a - 1) / a * a; }
 inline int conv_kpad(int K) { return round_up(K, 32); }

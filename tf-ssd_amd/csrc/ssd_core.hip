@@ -15,7 +15,7 @@ void set_error(const char* fmt, ...) {
 
 extern "C" {
 
-const char* ssd_version(void) { return "ssd_hip 0.1 (gfx950)"; }
+const char* ssd_version(void) { return "ssd_hip 0.2 (gfx950)"; }
 
 const char* ssd_last_error(void) { return ssd::g_err; }
 

@@ -1,0 +1,446 @@
+// Whole-image fused MobileNetV2 inverted-residual block for the low-resolution stages
+// (blocks 7-12 at 19x19 and 14-16 at 10x10 of SSD300; Cin 64 / 96 / 160):
+//
+//     y = project_BN( relu6(dw_BN( dw3x3( relu6(expand_BN( x * We )) ) )) * Wp ) [+ x]
+//
+// ([3P] keras-applications MobileNetV2 block_k_expand .. block_k_add, SURVEY.md Appendix A.)
+// The tile kernel of ssd_fused.hip recomputes a 1.6-1.9x expand halo around 8x8 tiles and needs
+// Cin <= 32; run as expand GEMM + depthwise/project kernel these blocks write the 6x expanded map
+// E to HBM and read it back (41-62 MB per layer at B=64).  At 19x19 / 10x10 a WHOLE image fits one
+// workgroup, so there is no halo at all: the image border is the zero padding.
+//
+//   workgroup = (image, group g of the G expanded-channel groups), 512 threads = 8 waves
+//   pixel space: q = r * P + c with pitch P = W + 1 -- the one pad column per row is the right
+//                padding of row r and the left padding of row r + 1; 16 consecutive q = one MFMA
+//                pixel tile, a wave owns T tiles for the whole kernel
+//   X  the wave's pixel tiles as MFMA B fragments, loaded ONCE from global into registers
+//   per 16-channel chunk of the group's Ce / G expanded channels (one LDS barrier per chunk,
+//   E and the weight chunks double-buffered):
+//     A  expand   E[q][16] = relu6(X[q][Cin] * We[Cin][16] + shift), 0 at pad positions -> LDS
+//     B  depthw.  D[q][16] = relu6(sum_taps E[q + dy*P + dx] * Wd + shift): each lane computes ITS
+//                 pixel x 4 channels, i.e. the MFMA B fragment of phase C, from 9 conflict-free
+//                 ds_read_b128 -- D never goes back to LDS
+//     C  project  acc[q][Cout] += D[q][16] * Wp[16][Cout]   accumulators in registers
+//   G > 1: each group holds a partial sum over its channels.  The groups of an image meet through
+//   an arrival ticket (agent-scope release / acquire, cdna_hip_programming.md "in-launch split-K
+//   reduction"): every group stores its fp32 slab, the last arriver adds the G slabs in group
+//   order (deterministic), the project BN shift and the residual, and writes y.
+//   G = 1 (B >= #CUs): direct epilogue.
+#include <cstdlib>
+
+#include "ssd_conv.h"
+
+namespace ssd {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+namespace {
+
+constexpr int kIC = 16;           // expanded channels per chunk
+constexpr int kILD = 24;          // LDS row stride (floats) of the E / Wp chunk tiles: 6 quads, conflict-free b128 fragments
+constexpr int kIThreads = 512;
+
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+// compiler-invisible prefetch loads + the matching hand-placed wait (idiom of ssd_fused.hip:
+// every issued load IS consumed)
+__device__ __forceinline__ f32x4 gload16_async(const float* ptr) {
+    f32x4 v;
+    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(v) : "v"(ptr) : "memory");
+    return v;
+}
+// write-through (sc1) 16-byte store: the slab lines do not stay dirty in this XCD's L2, so publishing
+// them needs no L2 write-back fence (cdna_hip_programming.md, in-launch split-K reduction)
+__device__ __forceinline__ void gstore16_sc1(float* ptr, f32x4 v) {
+    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(ptr), "v"(v) : "memory");
+}
+template <int N>
+__device__ __forceinline__ void wait_prefetch(f32x4 (&r)[N]) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int i = 0; i < N; ++i) asm volatile("" : "+v"(r[i]));
+}
+
+template <int CIN, int NT, int T>
+__global__ __launch_bounds__(kIThreads) void mbv2_image_block_kernel(const FusedBlockParams p) {
+    constexpr int KC = CIN / 16;                  // 16-wide k blocks of the expand
+    constexpr int LDW = CIN + 8;                  // We chunk row stride: 18 / 26 / 42 quads (2 mod 4)
+    constexpr int NCH = T == 1 ? 2 : 1;           // independent expand accumulator chains per tile
+    constexpr int WE_U = kIC * CIN / 4, WE_R = (WE_U + kIThreads - 1) / kIThreads;
+    constexpr int WP_U = NT * 16 * kIC / 4, WP_R = (WP_U + kIThreads - 1) / kIThreads;
+
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, g4 = lane >> 4;
+    const int G = p.groups, B = p.B;
+    // the G groups of an image are B block ids apart: the same XCD whenever B % 8 == 0 (speed only)
+    const int grp = blockIdx.x / B, img = blockIdx.x - grp * B;
+    const int H = p.H, W = p.W, P = W + 1, Q = H * P;
+    const int npt = (Q + 15) >> 4;
+    const int NE = npt * 16 + 2 * P + 2;          // E rows: index q + P + 1, zero rows above / below
+    const int CeG = p.Ce / G, cbeg = grp * CeG, nchunk = CeG / kIC;
+
+    float* Es = sm;                               // [2][NE][kILD]
+    float* Wes = Es + 2 * NE * kILD;              // [2][16][LDW]
+    float* Wps = Wes + 2 * kIC * LDW;             // [2][NT*16][kILD]
+    float* Ps = Wps + 2 * NT * 16 * kILD;         // [11][CeG]: expand shift, depthwise taps [9], depthwise shift
+    int* flag = reinterpret_cast<int*>(Ps + 11 * CeG);
+
+    // diagnostics (ssd_net_profile_fused): per-wave cycles of 0 prologue, 1 barrier wait, 2 depthwise,
+    // 3 project, 4 expand + weight staging, 5 epilogue / combine
+    long long tacc[6] = {0, 0, 0, 0, 0, 0};
+    long long t0 = p.dbg ? clock64() : 0;
+#define ITICK(i) do { if (p.dbg) { const long long t1 = clock64(); tacc[i] += t1 - t0; t0 = t1; } } while (0)
+#define IDUMP() do { if (p.dbg && lane == 0) for (int i_ = 0; i_ < 6; ++i_) p.dbg[((long)blockIdx.x * 8 + wave) * 6 + i_] = tacc[i_]; } while (0)
+
+    // ---- weight chunk prefetch (global -> registers -> LDS), one "set" = { Wp(j), We(j + 1) }
+    f32x4 wer[WE_R], wpr[WP_R];
+    auto load_we_to = [&](f32x4 (&r)[WE_R], int j) {
+#pragma unroll
+        for (int i = 0; i < WE_R; ++i) {
+            const int u = min(tid + i * kIThreads, WE_U - 1);
+            const int row = u / (CIN / 4), k4 = (u - row * (CIN / 4)) * 4;
+            r[i] = gload16_async(p.we + (long)(cbeg + j * kIC + row) * p.kpad_e + k4);
+        }
+    };
+    auto store_we_from = [&](const f32x4 (&r)[WE_R], int buf) {
+#pragma unroll
+        for (int i = 0; i < WE_R; ++i) {
+            const int u = tid + i * kIThreads;
+            const int row = u / (CIN / 4), k4 = (u - row * (CIN / 4)) * 4;
+            if (u < WE_U) *reinterpret_cast<f32x4*>(Wes + (buf * kIC + row) * LDW + k4) = r[i];
+        }
+    };
+    auto load_we = [&](int j) { load_we_to(wer, j); };
+    auto store_we = [&](int buf) { store_we_from(wer, buf); };
+    auto load_wp = [&](int j) {
+#pragma unroll
+        for (int i = 0; i < WP_R; ++i) {
+            const int u = min(tid + i * kIThreads, WP_U - 1);
+            const int row = u >> 2, k4 = (u & 3) * 4;
+            wpr[i] = gload16_async(p.wp + (long)row * p.kpad_p + cbeg + j * kIC + k4);
+        }
+    };
+    auto store_wp = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < WP_R; ++i) {
+            const int u = tid + i * kIThreads;
+            const int row = u >> 2, k4 = (u & 3) * 4;
+            if (u < WP_U) *reinterpret_cast<f32x4*>(Wps + (buf * NT * 16 + row) * kILD + k4) = wpr[i];
+        }
+    };
+
+    // ---- prologue: every global load of the start-up is in flight at once (weight chunks We(0),
+    //      We(1), Wp(0), the group's per-channel parameters, the wave's X fragments)
+    f32x4 wer0[WE_R];
+    load_we_to(wer0, 0);
+    if (nchunk > 1) load_we(1);
+    load_wp(0);
+    // E rows no expand ever writes (above the map, below its last pixel tile) are zero for good; the
+    // pad column and the tail of the last tile are written as zeros by every expand
+    for (int u = tid; u < 2 * (2 * P + 2) * (kILD / 4); u += kIThreads) {
+        const int buf = u / ((2 * P + 2) * (kILD / 4)), v = u - buf * ((2 * P + 2) * (kILD / 4));
+        const int row = v / (kILD / 4), c4 = (v - row * (kILD / 4)) * 4;
+        const int e = row < P + 1 ? row : npt * 16 + row;          // rows [0, P] and [npt*16 + P + 1, NE)
+        *reinterpret_cast<f32x4*>(Es + (buf * NE + e) * kILD + c4) = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    f32x4 xb[T][KC];
+    int qs[T];             // pixel index of this lane in tile t (0 for tiles beyond the map)
+    bool tvalid[T], real[T];
+    int opix[T];           // r * W + c of a real pixel
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+        const int tile = wave * T + t;
+        tvalid[t] = tile < npt;
+        const int q = tile * 16 + l15;
+        const int r = q / P, c = q - r * P;
+        real[t] = tvalid[t] && q < Q && c < W;
+        qs[t] = tvalid[t] ? q : 0;
+        opix[t] = real[t] ? r * W + c : 0;
+        const float* xp = p.x + ((long)img * H * W + opix[t]) * CIN + g4 * 4;
+#pragma unroll
+        for (int kc = 0; kc < KC; ++kc)
+            xb[t][kc] = real[t] ? *reinterpret_cast<const f32x4*>(xp + kc * 16) : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    for (int u = tid; u < 11 * (CeG / 4); u += kIThreads) {
+        const int row = u / (CeG / 4), c4 = (u - row * (CeG / 4)) * 4;
+        const float* src = row == 0 ? p.eh : row == 10 ? p.dh : p.wd + (long)(row - 1) * p.Ce;
+        *reinterpret_cast<f32x4*>(Ps + row * CeG + c4) = *reinterpret_cast<const f32x4*>(src + cbeg + c4);
+    }
+    wait_prefetch(wer0);
+    store_we_from(wer0, 0);
+    wait_prefetch(wpr);
+    store_wp(0);
+    if (nchunk > 1) { wait_prefetch(wer); store_we(1); }
+    __syncthreads();
+
+    auto expand = [&](int j) {
+        f32x4 ea[T][NCH];
+        const f32x4 sh = *reinterpret_cast<const f32x4*>(Ps + j * kIC + g4 * 4);
+#pragma unroll
+        for (int t = 0; t < T; ++t) {
+            ea[t][0] = sh;
+            if (NCH == 2) ea[t][NCH - 1] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        const float* wes = Wes + ((j & 1) * kIC + l15) * LDW + g4 * 4;
+        if (!(p.ablate & 1))
+#pragma unroll
+        for (int kc = 0; kc < KC; ++kc) {
+            const f32x4 wa = *reinterpret_cast<const f32x4*>(wes + kc * 16);
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+#pragma unroll
+                for (int t = 0; t < T; ++t)
+                    ea[t][kc % NCH] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[s], xb[t][kc][s], ea[t][kc % NCH], 0, 0, 0);
+        }
+        float* es = Es + ((j & 1) * NE + P + 1) * kILD + g4 * 4;
+#pragma unroll
+        for (int t = 0; t < T; ++t) {
+            f32x4 v = ea[t][0];
+            if (NCH == 2) v = v + ea[t][NCH - 1];
+            const float hi = real[t] ? 6.0f : 0.0f;       // relu6 at real pixels, 0 at pad positions
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = __builtin_amdgcn_fmed3f(v[e], 0.0f, hi);
+            if (tvalid[t]) *reinterpret_cast<f32x4*>(es + qs[t] * kILD) = v;
+        }
+    };
+
+    f32x4 acc[T][NT];
+#pragma unroll
+    for (int t = 0; t < T; ++t)
+#pragma unroll
+        for (int ni = 0; ni < NT; ++ni) acc[t][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    expand(0);
+    ITICK(0);
+    if (nchunk > 1) {           // set 1 = { Wp(1), We(2) } -> registers
+        load_wp(1);
+        if (nchunk > 2) load_we(2);
+    }
+
+    for (int i = 0; i < nchunk; ++i) {
+        lds_barrier();          // E(i) and weight set i are visible; everyone is done with interval i - 1
+        ITICK(1);
+        if (i + 1 < nchunk) {
+            wait_prefetch(wpr);
+            store_wp((i + 1) & 1);
+            if (i + 2 < nchunk) {
+                wait_prefetch(wer);
+                store_we(i & 1);
+                load_wp(i + 2);
+                if (i + 3 < nchunk) load_we(i + 3);
+            }
+        }
+        ITICK(4);
+        // ---- depthwise in MFMA-fragment layout
+        f32x4 a[T];
+        if (p.ablate & 2) {
+#pragma unroll
+            for (int t = 0; t < T; ++t) a[t] = f32x4{1.f, 1.f, 1.f, 1.f};
+        } else {
+            const f32x4 dh = *reinterpret_cast<const f32x4*>(Ps + 10 * CeG + i * kIC + g4 * 4);
+#pragma unroll
+            for (int t = 0; t < T; ++t) a[t] = dh;
+            const float* es = Es + ((i & 1) * NE + P + 1) * kILD + g4 * 4;
+#pragma unroll
+            for (int dy = -1; dy <= 1; ++dy)
+#pragma unroll
+                for (int dx = -1; dx <= 1; ++dx) {
+                    const f32x4 w = *reinterpret_cast<const f32x4*>(Ps + (1 + (dy + 1) * 3 + dx + 1) * CeG + i * kIC + g4 * 4);
+#pragma unroll
+                    for (int t = 0; t < T; ++t) {
+                        const f32x4 e = *reinterpret_cast<const f32x4*>(es + (qs[t] + dy * P + dx) * kILD);
+                        a[t] += e * w;
+                    }
+                }
+#pragma unroll
+            for (int t = 0; t < T; ++t)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) a[t][e] = __builtin_amdgcn_fmed3f(a[t][e], 0.0f, 6.0f);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        ITICK(2);
+        // ---- project
+        if (!(p.ablate & 4)) {
+            const float* wps = Wps + ((i & 1) * NT * 16 + l15) * kILD + g4 * 4;
+#pragma unroll
+            for (int ni = 0; ni < NT; ++ni) {
+                const f32x4 wa = *reinterpret_cast<const f32x4*>(wps + ni * 16 * kILD);
+#pragma unroll
+                for (int s = 0; s < 4; ++s)
+#pragma unroll
+                    for (int t = 0; t < T; ++t)
+                        acc[t][ni] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[s], a[t][s], acc[t][ni], 0, 0, 0);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        ITICK(3);
+        if (i + 1 < nchunk) expand(i + 1);
+        ITICK(4);
+    }
+
+    // ---- epilogue
+    const long img_off = (long)img * H * W * p.Cout;
+    if (G == 1) {
+#pragma unroll
+        for (int t = 0; t < T; ++t) {
+            if (!real[t]) continue;
+            float* yp = p.y + img_off + (long)opix[t] * p.Cout + g4 * 4;
+#pragma unroll
+            for (int ni = 0; ni < NT; ++ni) {
+                f32x4 v = acc[t][ni] + *reinterpret_cast<const f32x4*>(p.ph + ni * 16 + g4 * 4);
+                if (p.residual)                                     // Cin == Cout: same layout as y
+                    v = v + *reinterpret_cast<const f32x4*>(p.x + img_off + (long)opix[t] * p.Cout + ni * 16 + g4 * 4);
+                *reinterpret_cast<f32x4*>(yp + ni * 16) = v;
+            }
+        }
+        ITICK(5);
+        IDUMP();
+        return;
+    }
+    if (p.ablate & 16) return;
+    const long slab_stride = (long)B * H * W * p.Cout;              // between groups
+    {
+        float* sp = p.slabs + (long)grp * slab_stride + img_off + g4 * 4;
+#pragma unroll
+        for (int t = 0; t < T; ++t) {
+            if (!real[t]) continue;
+#pragma unroll
+            for (int ni = 0; ni < NT; ++ni)
+                gstore16_sc1(sp + (long)opix[t] * p.Cout + ni * 16, acc[t][ni]);
+        }
+    }
+    // publish the slab, draw a ticket; the last arriver of the image combines
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) {
+        const unsigned old = __hip_atomic_fetch_add(p.tickets + img, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int last = old == (unsigned)(G - 1);
+        if (last) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            __hip_atomic_store(p.tickets + img, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
+        }
+        flag[0] = last;
+    }
+    __syncthreads();
+    if (!flag[0] || (p.ablate & 8)) {
+        ITICK(5);
+        IDUMP();
+        return;
+    }
+    // last arriver: y = shift + sum of the G partial sums in GROUP order (deterministic whoever
+    // arrives last) + residual, as one coalesced pass over the image.  (Measured: this pass runs at
+    // ~30 GB/s -- one CU's outstanding-miss budget at the loaded ~2-3 us latency -- whichever way
+    // the loads are batched; fetching only the other groups' values in accumulator layout, or four
+    // groups per round trip, changed nothing.)
+    {
+        const int c4n = p.Cout / 4;
+        const int nvec = H * W * c4n;
+        const float* s0 = p.slabs + img_off;
+        const float* xr = p.x + img_off;                             // residual: Cin == Cout, same layout
+        float* yo = p.y + img_off;
+#pragma unroll 2
+        for (int e = tid; e < nvec; e += kIThreads) {
+            const int n4 = (e % c4n) * 4;
+            f32x4 v = *reinterpret_cast<const f32x4*>(p.ph + n4);
+            f32x4 s[8];
+            for (int g0 = 0; g0 < G; g0 += 8) {
+#pragma unroll
+                for (int gg = 0; gg < 8; ++gg)
+                    if (g0 + gg < G) s[gg] = *reinterpret_cast<const f32x4*>(s0 + (long)(g0 + gg) * slab_stride + (long)e * 4);
+#pragma unroll
+                for (int gg = 0; gg < 8; ++gg)
+                    if (g0 + gg < G) v = v + s[gg];
+            }
+            if (p.residual) v = v + *reinterpret_cast<const f32x4*>(xr + (long)e * 4);
+            *reinterpret_cast<f32x4*>(yo + (long)e * 4) = v;
+        }
+    }
+    ITICK(5);
+    IDUMP();
+#undef ITICK
+#undef IDUMP
+}
+
+typedef void (*image_kernel_t)(const FusedBlockParams);
+struct ImageCfg {
+    int cin, nt, t;
+    image_kernel_t fn;
+};
+#define ICFG(CIN, NT, T) {CIN, NT, T, mbv2_image_block_kernel<CIN, NT, T>}
+const ImageCfg kImage[] = {
+    ICFG(64, 4, 3),     // blocks 7-9:   64 -> 384 -> 64 at 19x19
+    ICFG(64, 6, 3),     // block 10:     64 -> 384 -> 96
+    ICFG(96, 6, 3),     // blocks 11-12: 96 -> 576 -> 96
+    ICFG(160, 10, 1),   // blocks 14-15: 160 -> 960 -> 160 at 10x10
+    ICFG(160, 20, 1),   // block 16:     160 -> 960 -> 320
+};
+
+size_t image_lds_bytes(const ImageCfg& c, const FusedBlockParams& p, int G) {
+    const int P = p.W + 1, npt = (p.H * P + 15) / 16, NE = npt * 16 + 2 * P + 2;
+    const size_t fl = (size_t)2 * NE * kILD + (size_t)2 * kIC * (c.cin + 8) + (size_t)2 * c.nt * 16 * kILD +
+                      (size_t)11 * (p.Ce / G) + 4;
+    return fl * sizeof(float);
+}
+
+const ImageCfg* pick_image(const FusedBlockParams& p) {
+    if (p.stride != 1 || p.H != p.Ho || p.W != p.Wo || p.Ce % kIC != 0 || p.Cout % 16 != 0) return nullptr;
+    if (p.kpad_e % 4 != 0 || p.kpad_p % 4 != 0) return nullptr;
+    if (p.residual && p.Cin != p.Cout) return nullptr;
+    const int npt = (p.H * (p.W + 1) + 15) / 16;
+    for (const auto& c : kImage)
+        if (c.cin == p.Cin && c.nt * 16 == p.Cout && npt <= 8 * c.t && npt > 8 * (c.t == 3 ? 1 : 0) &&
+            image_lds_bytes(c, p, 1) + 11 * p.Ce * 0 <= 160 * 1024)
+            return &c;
+    return nullptr;
+}
+
+}  // namespace
+
+bool image_block_supported(const FusedBlockParams& p) { return pick_image(p) != nullptr; }
+
+// Number of expanded-channel groups for batch B: the smallest divisor of Ce / 16 that fills the
+// CUs (one workgroup per CU: 78-120 KB of LDS), at most 12.
+int image_block_groups(const FusedBlockParams& p, int B) {
+    static int num_cu = 0;
+    if (!num_cu) {
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        if (hipDeviceGetAttribute(&num_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || num_cu <= 0)
+            num_cu = 256;
+    }
+    const int units = p.Ce / kIC;
+    int best = 1;
+    for (int g = 1; g <= 12 && g <= units; ++g) {
+        if (units % g) continue;
+        best = g;
+        if ((long)B * g * 8 >= (long)num_cu * 7) break;
+    }
+    return best;
+}
+
+size_t image_block_slab_floats(const FusedBlockParams& p, int B) {
+    const int G = image_block_groups(p, B);
+    return G > 1 ? (size_t)G * B * p.H * p.W * p.Cout : 0;
+}
+
+int launch_image_block(FusedBlockParams p, hipStream_t st) {
+    const ImageCfg* c = pick_image(p);
+    if (!c) {
+        set_error("image block: unsupported shape Cin=%d Ce=%d Cout=%d %dx%d stride=%d", p.Cin, p.Ce, p.Cout, p.H, p.W, p.stride);
+        return SSD_E_UNSUPPORTED;
+    }
+    if (p.B == 0) return SSD_OK;
+    if (p.groups < 1) p.groups = 1;
+    static const int ablate = getenv("SSD_IMAGE_ABLATE") ? atoi(getenv("SSD_IMAGE_ABLATE")) : 0;
+    if (!p.ablate) p.ablate = ablate;
+    SSD_CHECK_ARG((p.Ce / kIC) % p.groups == 0, "image block: %d groups do not divide Ce/16 = %d", p.groups, p.Ce / kIC);
+    SSD_CHECK_ARG(p.groups == 1 || (p.slabs && p.tickets), "image block: %d groups need the slab workspace", p.groups);
+    const size_t lds = image_lds_bytes(*c, p, p.groups);
+    SSD_UNSUPPORTED_IF(lds > 160 * 1024, "image block: needs %zu B of LDS", lds);
+    if (lds > 64 * 1024)
+        SSD_HIP(hipFuncSetAttribute((const void*)c->fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(c->fn, dim3((unsigned)((long)p.B * p.groups)), dim3(kIThreads), lds, st, p);
+    SSD_LAUNCH_CHECK();
+    return SSD_OK;
+}
+
+}  // namespace ssd

@@ -58,6 +58,7 @@ struct Layer {
     int f_type = 0;                 // 0: inverted-residual block, 1: stem (Conv1 -> dw -> project),
                                     // 2: depthwise + project (the expand conv stays a GEMM of its own)
     int fused_by = -1;
+    int img_choice = -1;            // whole-block LK_FUSED layers the image kernel can run: 1 = it won the finalize-time race against the layer kernels, 0 = it lost, -1 = not timed
     int fused_by2 = -1;             // depthwise / project members: their type-2 LK_FUSED layer
     float* splitk_part = nullptr;   // this layer's own split-K slab (layers may run concurrently)
     // LK_FUSED: weight copies with the folded BatchNorm scale multiplied in (per output channel)
@@ -83,6 +84,9 @@ struct ssd_net {
     bool fuse_blocks = true;        // run eligible inverted-residual blocks as one fused kernel
     bool fuse_dwproj = true;        // ... and depthwise + project of the others as one kernel
     bool use_wino = true;           // offer the Winograd F(2x2,3x3) kernels to the autotune
+    int fuse_image = 1;             // whole-image block kernel (ssd_imgblock.hip): 0 never, 1 where it won the finalize-time race, 2 wherever it applies
+    float* img_slabs = nullptr;     // its partial-sum slabs and arrival tickets (sized for max_batch)
+    unsigned* img_tickets = nullptr;
     int max_batch = 0;
     int last_batch = 0;
     std::vector<float*> owned;      // device allocations to free

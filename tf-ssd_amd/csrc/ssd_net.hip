@@ -350,6 +350,11 @@ static FusedBlockParams fused_params(const ssd_net& net, const Layer& f, int B) 
     p.kpad_e = conv_kpad(le.Cin);
     p.kpad_p = conv_kpad(lp.Cin);
     p.npad_p = conv_npad(lp.Cout);
+    if (!fused_block_supported(p) && image_block_supported(p)) {
+        p.groups = net.img_slabs ? image_block_groups(p, B) : 1;
+        p.slabs = net.img_slabs;
+        p.tickets = net.img_tickets;
+    }
     return p;
 }
 
@@ -422,7 +427,10 @@ static int run_layer_impl(ssd_net& net, const Layer& l, int B, float* deltas_out
         case LK_FUSED:
             if (l.f_type == 1) return launch_stem(stem_params(net, l, B), st);
             if (l.f_type == 2) return launch_dwproj(dwproj_params(net, l, B), st);
-            return launch_fused_block(fused_params(net, l, B), st);
+            {
+                const FusedBlockParams p = fused_params(net, l, B);
+                return fused_block_supported(p) ? launch_fused_block(p, st) : launch_image_block(p, st);
+            }
     }
     return SSD_OK;
 }
@@ -437,7 +445,10 @@ static bool fused_active(const ssd_net& net, const Layer& f) {
         if (f.fused_by >= 0 && fused_active(net, net.layers[f.fused_by])) return false;   // whole block fused
         return dwproj_supported(dwproj_params(net, f, 1));
     }
-    return fused_block_supported(fused_params(net, f, 1));
+    const FusedBlockParams p = fused_params(net, f, 1);
+    if (fused_block_supported(p)) return true;
+    if (!net.fuse_image || (net.fuse_image == 1 && f.img_choice != 1)) return false;
+    return image_block_supported(p);
 }
 static bool layer_runs(const ssd_net& net, const Layer& l) {
     if (l.kind == LK_FUSED) return fused_active(net, l);
@@ -465,6 +476,43 @@ struct ScopedEvent {
     hipEvent_t e = nullptr;
     ~ScopedEvent() { if (e) (void)hipEventDestroy(e); }
 };
+
+// Whole-image block kernel vs the layer kernels (expand GEMM + depthwise/project kernel) of the
+// same block, timed on the device at batch B: at B = 64 the 4-way channel-group reduction costs
+// what the E round trip through HBM costs, at large batches (one group) the image kernel wins.
+static int tune_image_blocks(ssd_net& net, int B, hipStream_t st) {
+    ScopedEvent se0, se1;
+    SSD_HIP(hipEventCreate(&se0.e));
+    SSD_HIP(hipEventCreate(&se1.e));
+    const int mode = net.fuse_image;
+    net.fuse_image = 1;
+    int rc = SSD_OK;
+    for (size_t fi = 0; fi < net.layers.size() && !rc; ++fi) {
+        Layer& f = net.layers[fi];
+        if (f.kind != LK_FUSED || f.f_type != 0) continue;
+        const FusedBlockParams p = fused_params(net, f, B);
+        if (fused_block_supported(p) || !image_block_supported(p)) { f.img_choice = 0; continue; }
+        float ms[2] = {1e30f, 1e30f};
+        for (int choice = 0; choice < 2 && !rc; ++choice) {
+            f.img_choice = choice;
+            for (int trial = 0; trial < 4 && !rc; ++trial) {        // trial 0 warms up
+                (void)hipEventRecord(se0.e, st);
+                for (int r = 0; r < 4 && !rc; ++r)
+                    for (int j = (int)fi; j <= f.f_project && !rc; ++j)
+                        if (layer_runs(net, net.layers[j])) rc = run_layer(net, net.layers[j], B, nullptr, nullptr, st);
+                (void)hipEventRecord(se1.e, st);
+                if (rc) break;
+                SSD_HIP(hipEventSynchronize(se1.e));
+                float t = 0.f;
+                (void)hipEventElapsedTime(&t, se0.e, se1.e);
+                if (trial && t < ms[choice]) ms[choice] = t;
+            }
+        }
+        f.img_choice = ms[1] < ms[0] ? 1 : 0;
+    }
+    net.fuse_image = mode;
+    return rc;
+}
 
 static int autotune(ssd_net& net, int B, hipStream_t st) {
     ScopedEvent se0, se1;
@@ -770,6 +818,27 @@ int ssd_net_finalize(ssd_net* net, int max_batch) {
         if (!rc) rc = launch_scale_rows(lp.packed, lp.scale, conv_npad(lp.Cout), lp.Cout, conv_kpad(lp.Cin), f.fz_wp, st);
         if (rc) return rc;
     }
+    // whole-image block kernel: slab workspace for the largest (groups x batch) product any batch
+    // up to max_batch can ask for, and the arrival tickets (zero between launches)
+    {
+        size_t slab = 0;
+        for (auto& f : net->layers) {
+            if (f.kind != LK_FUSED || f.f_type != 0) continue;
+            const FusedBlockParams p = fused_params(*net, f, 1);
+            if (fused_block_supported(p) || !image_block_supported(p)) continue;
+            for (int b = 1; b <= max_batch; ++b) slab = std::max(slab, image_block_slab_floats(p, b));
+        }
+        net->img_slabs = nullptr;
+        net->img_tickets = nullptr;
+        if (slab) {
+            float* tk = nullptr;
+            int rc = dev_alloc(*net, slab, &net->img_slabs);
+            if (!rc) rc = dev_alloc(*net, (size_t)max_batch, &tk);
+            if (rc) return rc;
+            net->img_tickets = reinterpret_cast<unsigned*>(tk);
+            SSD_HIP(hipMemsetAsync(tk, 0, (size_t)max_batch * sizeof(unsigned), st));
+        }
+    }
     // activation arena: one slot per tensor (288 GB of HBM: no aliasing needed, every
     // activation of the last forward stays inspectable)
     if (net->arena) (void)hipFree(net->arena);
@@ -808,6 +877,16 @@ int ssd_net_finalize(ssd_net* net, int max_batch) {
                                          net->arena, net->arena);
         if (!conv_config_valid(cfg, p)) { preset_ok = false; break; }
         if (l.split_k > 1) ws_need = std::max(ws_need, (size_t)l.split_k * p.M * p.Cout);
+    }
+    bool image_preset_ok = true;
+    for (auto& f : net->layers) {       // whole-block layers the image kernel can run: "name image 0|1"
+        if (f.kind != LK_FUSED || f.f_type != 0) continue;
+        f.img_choice = -1;
+        const FusedBlockParams p = fused_params(*net, f, 1);
+        if (fused_block_supported(p) || !image_block_supported(p)) continue;
+        auto it = net->preset.find(f.name);
+        if (it == net->preset.end() || it->second.first != "image") { image_preset_ok = false; continue; }
+        f.img_choice = it->second.second ? 1 : 0;
     }
     int rc = SSD_OK;
     if (preset_ok) {
@@ -848,6 +927,10 @@ int ssd_net_finalize(ssd_net* net, int max_batch) {
         for (auto& l : net->layers)
             if (!l.ev_ready) SSD_HIP(hipEventCreateWithFlags(&l.ev_ready, hipEventDisableTiming));
     }
+    if (!preset_ok || !image_preset_ok) {
+        rc = tune_image_blocks(*net, max_batch, st);
+        if (rc) return rc;
+    }
     SSD_HIP(hipDeviceSynchronize());
     net->drop_graphs();
     net->finalized = true;
@@ -861,6 +944,12 @@ long ssd_net_get_tuning(const ssd_net* net, char* buf, size_t cap) {
     for (const auto& l : net->layers)
         if (l.kind == LK_CONV && l.cfg >= 0)
             out += l.name + " " + conv_config_name(l.cfg) + " " + std::to_string(l.split_k) + "\n";
+    for (const auto& l : net->layers)
+        if (l.kind == LK_FUSED && l.f_type == 0 && l.img_choice >= 0) {
+            const FusedBlockParams p = fused_params(*net, l, 1);
+            if (!fused_block_supported(p) && image_block_supported(p))
+                out += l.name + " image " + std::to_string(l.img_choice) + "\n";
+        }
     if (buf && cap > out.size()) memcpy(buf, out.c_str(), out.size() + 1);
     return (long)out.size();
 }
@@ -877,7 +966,7 @@ int ssd_net_set_tuning(ssd_net* net, const char* text) {
         pos = e + 1;
         char name[128], cfg[128];
         int split = 1;
-        if (sscanf(line.c_str(), "%127s %127s %d", name, cfg, &split) == 3 && split >= 1 && split <= 64)
+        if (sscanf(line.c_str(), "%127s %127s %d", name, cfg, &split) == 3 && split >= (std::string(cfg) == "image" ? 0 : 1) && split <= 64)
             net->preset[name] = {cfg, split};
     }
     net->finalized = false;
@@ -1086,14 +1175,16 @@ int ssd_net_profile_fused(ssd_net* net, const char* layer, int B, double* cycles
         if (l.kind == LK_FUSED && l.f_type == 0 && l.name == layer) f = &l;
     SSD_CHECK_ARG(f != nullptr, "ssd_net_profile_fused: unknown fused layer '%s'", layer);
     FusedBlockParams p = fused_params(*net, *f, B);
-    SSD_CHECK_ARG(fused_block_supported(p), "ssd_net_profile_fused: layer not supported by the fused kernel");
+    const bool image = !fused_block_supported(p) && image_block_supported(p);
+    SSD_CHECK_ARG(fused_block_supported(p) || image, "ssd_net_profile_fused: layer not supported by the fused kernels");
+    auto launch = [&](const FusedBlockParams& q) { return image ? launch_image_block(q, nullptr) : launch_fused_block(q, nullptr); };
     if (const char* ab = getenv("SSD_FUSED_ABLATE")) {      // diagnostics: time the kernel with phases removed
         p.ablate = atoi(ab);
         hipEvent_t e0, e1;
         (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
-        (void)launch_fused_block(p, nullptr);
+        (void)launch(p);
         (void)hipEventRecord(e0, nullptr);
-        for (int r = 0; r < 10; ++r) (void)launch_fused_block(p, nullptr);
+        for (int r = 0; r < 10; ++r) (void)launch(p);
         (void)hipEventRecord(e1, nullptr);
         (void)hipEventSynchronize(e1);
         float ms = 0.f;
@@ -1108,7 +1199,7 @@ int ssd_net_profile_fused(ssd_net* net, const char* layer, int B, double* cycles
     SSD_HIP(hipMalloc((void**)&d, n * sizeof(long long)));
     SSD_HIP(hipMemset(d, 0, n * sizeof(long long)));
     p.dbg = d;
-    int rc = launch_fused_block(p, nullptr);
+    int rc = launch(p);
     if (!rc && hipDeviceSynchronize() != hipSuccess) rc = SSD_E_HIP;
     if (!rc) {
         std::vector<long long> h(n);
@@ -1130,6 +1221,11 @@ int ssd_net_set_option(ssd_net* net, const char* name, int value) {
     SSD_CHECK_ARG(net && name, "ssd_net_set_option: NULL argument");
     if (std::string(name) == "fuse_blocks") {
         net->fuse_blocks = value != 0;
+        net->drop_graphs();
+        return SSD_OK;
+    }
+    if (std::string(name) == "fuse_image") {
+        net->fuse_image = value < 0 ? 0 : (value > 2 ? 2 : value);
         net->drop_graphs();
         return SSD_OK;
     }
