@@ -497,12 +497,13 @@ def test_forward_parity_with_poisoned_arena(backbone, monkeypatch):
         _abs(_np(d), rd)
 
 
-@pytest.mark.parametrize("B", [1, 5, 24, 232])
-def test_image_block_kernel_vs_layer_kernels(B):
+@pytest.mark.parametrize("B,ticket", [(1, 0), (5, 0), (5, 1), (24, 1), (64, 0), (232, 0)])
+def test_image_block_kernel_vs_layer_kernels(B, ticket):
     """Whole-image inverted-residual kernel (csrc/ssd_imgblock.hip; blocks 7-12, 14-16) against the
     expand GEMM + depthwise/project kernels on the same weights: B = 1 / 5 take 12 channel groups per
-    image whose slabs cross XCDs (ticket + last-arriver combine), B = 24 takes 8-10 groups, B = 232
-    the direct one-group epilogue.  Run twice: bitwise repeatable (fixed group summation order)."""
+    image, B = 24 takes 8-10, B = 64 four, B = 232 the direct one-group epilogue.  The group slabs are
+    combined by a second launch (default) or inside the launch by the last arriving group of each image
+    (image_ticket: slabs cross XCDs).  Run twice: bitwise repeatable (fixed group summation order)."""
     from models.ssd_mobilenet_v2 import get_model
     hp = helpers.hyper_params("mobilenet_v2")
     w = helpers.synthetic_weights("mobilenet_v2", hp)
@@ -516,6 +517,7 @@ def test_image_block_kernel_vs_layer_kernels(B):
     d0, p0 = m(x)
     ref = {n: m.fetch_activation(n).copy() for n in names}
     assert not any(l["name"] == "block_7_fused" and l["flops"] > 0 for l in m.layers(B))
+    m.set_option("image_ticket", ticket)
     m.set_option("fuse_image", 2)       # 2: wherever the kernel applies (1 = where it won the finalize-time race)
     d1, p1 = m(x)
     assert any(l["name"] == "block_7_fused" and l["flops"] > 0 for l in m.layers(B))

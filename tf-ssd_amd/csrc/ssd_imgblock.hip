@@ -21,11 +21,13 @@
 //                 pixel x 4 channels, i.e. the MFMA B fragment of phase C, from 9 conflict-free
 //                 ds_read_b128 -- D never goes back to LDS
 //     C  project  acc[q][Cout] += D[q][16] * Wp[16][Cout]   accumulators in registers
-//   G > 1: each group holds a partial sum over its channels.  The groups of an image meet through
-//   an arrival ticket (agent-scope release / acquire, cdna_hip_programming.md "in-launch split-K
-//   reduction"): every group stores its fp32 slab, the last arriver adds the G slabs in group
-//   order (deterministic), the project BN shift and the residual, and writes y.
-//   G = 1 (B >= #CUs): direct epilogue.
+//   G > 1: each group holds a partial sum over its channels and stores it as an fp32 slab; y = project
+//   BN shift + the G slabs added in group order (deterministic) + residual.  Default: a second,
+//   chip-wide launch (image_combine_kernel) does that sum.  Option "image_ticket": the groups of an
+//   image meet through an arrival ticket inside the launch (write-through slab stores, agent-scope
+//   acquire by the last arriver; cdna_hip_programming.md "in-launch split-K reduction") -- correct for
+//   any placement, but the one combining CU per image reads its 370-550 KB at ~30 GB/s (14-21 us).
+//   G = 1 (B >= #CUs): direct epilogue, no slabs.
 #include <cstdlib>
 
 #include "ssd_conv.h"
@@ -305,8 +307,14 @@ __global__ __launch_bounds__(kIThreads) void mbv2_image_block_kernel(const Fused
             if (!real[t]) continue;
 #pragma unroll
             for (int ni = 0; ni < NT; ++ni)
-                gstore16_sc1(sp + (long)opix[t] * p.Cout + ni * 16, acc[t][ni]);
+                if (p.tickets) gstore16_sc1(sp + (long)opix[t] * p.Cout + ni * 16, acc[t][ni]);
+                else *reinterpret_cast<f32x4*>(sp + (long)opix[t] * p.Cout + ni * 16) = acc[t][ni];
         }
+    }
+    if (!p.tickets) {        // combine by the follow-up kernel (image_combine_kernel): the launch boundary publishes the slabs
+        ITICK(5);
+        IDUMP();
+        return;
     }
     // publish the slab, draw a ticket; the last arriver of the image combines
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -358,6 +366,26 @@ __global__ __launch_bounds__(kIThreads) void mbv2_image_block_kernel(const Fused
     IDUMP();
 #undef ITICK
 #undef IDUMP
+}
+
+// y = shift + sum of the G slabs in group order (+ residual): the combine as its own launch
+__global__ __launch_bounds__(256) void image_combine_kernel(const float* __restrict__ slabs, const float* __restrict__ ph,
+                                                            const float* __restrict__ xres, float* __restrict__ y,
+                                                            long nvec, long slab_vec, int G, int c4n) {
+    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < nvec; e += (long)gridDim.x * 256) {
+        f32x4 v = *reinterpret_cast<const f32x4*>(ph + (e % c4n) * 4);
+        f32x4 s[4];
+        for (int g0 = 0; g0 < G; g0 += 4) {
+#pragma unroll
+            for (int gg = 0; gg < 4; ++gg)
+                if (g0 + gg < G) s[gg] = *reinterpret_cast<const f32x4*>(slabs + ((long)(g0 + gg) * slab_vec + e) * 4);
+#pragma unroll
+            for (int gg = 0; gg < 4; ++gg)
+                if (g0 + gg < G) v = v + s[gg];
+        }
+        if (xres) v = v + *reinterpret_cast<const f32x4*>(xres + e * 4);
+        *reinterpret_cast<f32x4*>(y + e * 4) = v;
+    }
 }
 
 typedef void (*image_kernel_t)(const FusedBlockParams);
@@ -433,13 +461,23 @@ int launch_image_block(FusedBlockParams p, hipStream_t st) {
     static const int ablate = getenv("SSD_IMAGE_ABLATE") ? atoi(getenv("SSD_IMAGE_ABLATE")) : 0;
     if (!p.ablate) p.ablate = ablate;
     SSD_CHECK_ARG((p.Ce / kIC) % p.groups == 0, "image block: %d groups do not divide Ce/16 = %d", p.groups, p.Ce / kIC);
-    SSD_CHECK_ARG(p.groups == 1 || (p.slabs && p.tickets), "image block: %d groups need the slab workspace", p.groups);
+    SSD_CHECK_ARG(p.groups == 1 || p.slabs, "image block: %d groups need the slab workspace", p.groups);
     const size_t lds = image_lds_bytes(*c, p, p.groups);
     SSD_UNSUPPORTED_IF(lds > 160 * 1024, "image block: needs %zu B of LDS", lds);
     if (lds > 64 * 1024)
         SSD_HIP(hipFuncSetAttribute((const void*)c->fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    // groups > 1: p.tickets == nullptr (default) combines the group slabs in a second launch -- the
+    // launch boundary publishes them and every CU takes part (B=64: 43 us per block 7 instead of 46);
+    // with tickets the last arriving group of each image combines inside the launch.
     hipLaunchKernelGGL(c->fn, dim3((unsigned)((long)p.B * p.groups)), dim3(kIThreads), lds, st, p);
     SSD_LAUNCH_CHECK();
+    if (p.groups > 1 && !p.tickets && !(p.ablate & 24)) {
+        const long nvec = (long)p.B * p.H * p.W * p.Cout / 4;
+        const int blocks = (int)((nvec + 255) / 256 < 4096 ? (nvec + 255) / 256 : 4096);
+        hipLaunchKernelGGL(image_combine_kernel, dim3(blocks), dim3(256), 0, st, p.slabs, p.ph, p.residual ? p.x : nullptr, p.y,
+                           nvec, nvec, p.groups, p.Cout / 4);
+        SSD_LAUNCH_CHECK();
+    }
     return SSD_OK;
 }
 

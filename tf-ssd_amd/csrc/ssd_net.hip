@@ -353,7 +353,7 @@ static FusedBlockParams fused_params(const ssd_net& net, const Layer& f, int B) 
     if (!fused_block_supported(p) && image_block_supported(p)) {
         p.groups = net.img_slabs ? image_block_groups(p, B) : 1;
         p.slabs = net.img_slabs;
-        p.tickets = net.img_tickets;
+        p.tickets = net.image_ticket ? net.img_tickets : nullptr;
     }
     return p;
 }
@@ -1226,6 +1226,11 @@ int ssd_net_set_option(ssd_net* net, const char* name, int value) {
     }
     if (std::string(name) == "fuse_image") {
         net->fuse_image = value < 0 ? 0 : (value > 2 ? 2 : value);
+        net->drop_graphs();
+        return SSD_OK;
+    }
+    if (std::string(name) == "image_ticket") {
+        net->image_ticket = value != 0;
         net->drop_graphs();
         return SSD_OK;
     }
