@@ -5,7 +5,12 @@ rows = list(csv.DictReader(open(f)))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 # a step starts at mbv2_stem_kernel
 starts = [i for i, r in enumerate(rows) if "mbv2_stem_kernel" in r["Kernel_Name"]]
-k = int(sys.argv[2]) if len(sys.argv) > 2 else -2
+spans = [(int(rows[starts[i + 1]]["Start_Timestamp"]) - int(rows[starts[i]]["Start_Timestamp"])) / 1e3 for i in range(len(starts) - 1)]
+print("step spans (us):", " ".join("%.0f" % v for v in spans))
+if len(sys.argv) > 2:
+    k = int(sys.argv[2])
+else:       # the shortest step = a graph-replayed one (the per-layer timing leg has event gaps)
+    k = min(range(len(spans)), key=lambda i: spans[i])
 i0 = starts[k]
 i1 = starts[k + 1]
 t0 = int(rows[i0]["Start_Timestamp"])

@@ -1000,7 +1000,95 @@ static int forward_impl(ssd_net* net, const float* image_dev, int B, float* delt
         (void)hipEventRecord((*ev)[0], st);
     }
     const bool overlap = net->overlap_heads && !net->timing && net->side[0];
-    // which layers feed a side-stream layer (their completion must be published)
+    // Stream plan (matters under hipGraph replay too: ready nodes start in capture order).  Every
+    // kernel of the heavy part of the graph fills the whole GPU, so overlapping two of them only splits
+    // the machine (measured: head 1 beside block 13's depthwise+project -> 239 + 212 us instead of
+    // 187 + 37).  What CAN hide is the latency-bound tail behind feature map 3 (extras 2-4, heads 3-6:
+    // ~150 us of 5-20 us kernels).  Shipped plan:
+    //   main stream : backbone ... producer of feature map 3, then the extras chain, (join) softmax
+    //   side[0]     : the two big head convs (side == 1), captured right behind feature map 3's producer
+    //                 (launching their split-K reduces behind BOTH of them instead of in between: no change)
+    //   side[1]     : the small heads (side == 2), each right behind its producer
+    // SSD_TAIL_ON_SIDE=1 swaps the roles (big heads back to back on the main stream, the tail on the
+    // side streams): measured 2.07 instead of 1.99 ms -- beside a head conv whose workgroups hold every
+    // CU's LDS / VGPRs a 10 us tail kernel waits for retiring workgroups (120-150 us each), and the
+    // dependent tail chain then outlives the heads.  In the shipped plan the executor starts head 1
+    // ~80 us after the backbone, i.e. the first third of the tail runs alone and un-starved.
+    const int nl = (int)net->layers.size();
+    static const bool tail_on_side = getenv("SSD_TAIL_ON_SIDE") ? atoi(getenv("SSD_TAIL_ON_SIDE")) != 0 : false;
+    std::vector<int> sid(nl, -1);           // -1 main, 0 / 1 side stream
+    std::vector<size_t> order;
+    order.reserve(nl);
+    if (overlap) {
+        int split = -1;                     // producer of the first small head's input
+        for (int j = 0; j < nl && split < 0; ++j) {
+            const Layer& h = net->layers[j];
+            if (h.side != 2 || !layer_runs(*net, h)) continue;
+            for (int q = j - 1; q >= 0; --q)
+                if (net->layers[q].out == h.in && layer_runs(*net, net->layers[q])) { split = q; break; }
+        }
+        std::vector<char> placed(nl, 0);
+        auto place_small_heads = [&](int out_tensor) {
+            for (int j = 0; j < nl; ++j) {
+                const Layer& c = net->layers[j];
+                if (placed[j] || c.side != 2 || c.in != out_tensor || !layer_runs(*net, c)) continue;
+                placed[j] = 1;
+                sid[j] = 1;
+                order.push_back(j);
+            }
+        };
+        for (int i = 0; i < nl; ++i) {      // main chain up to the split
+            const Layer& l = net->layers[i];
+            if (l.side || l.kind == LK_SOFTMAX || (split >= 0 && i > split)) continue;
+            order.push_back(i);
+            placed[i] = 1;
+        }
+        for (int i = 0; i < nl; ++i) {      // big heads: main stream, right behind the split layer
+            if (net->layers[i].side != 1) continue;
+            // (VGG16: the L2 normalisation feeding head 1 sits behind the extras in the layer list)
+            for (int j = i - 1; j >= 0; --j)
+                if (net->layers[j].out == net->layers[i].in && layer_runs(*net, net->layers[j])) {
+                    if (!placed[j]) { order.push_back(j); placed[j] = 1; }
+                    break;
+                }
+            order.push_back(i);
+            placed[i] = 1;
+            if (!tail_on_side) sid[i] = 0;
+        }
+        if (split >= 0) place_small_heads(net->layers[split].out);
+        for (int i = 0; i < nl; ++i) {      // tail chain (+ its small heads right behind their producers)
+            const Layer& l = net->layers[i];
+            if (placed[i] || l.side || l.kind == LK_SOFTMAX) continue;
+            sid[i] = tail_on_side ? 0 : -1;
+            order.push_back(i);
+            placed[i] = 1;
+            if (l.out > 0 && layer_runs(*net, l)) place_small_heads(l.out);
+        }
+        for (int i = 0; i < nl; ++i)        // anything left (small heads without a running producer), then softmax
+            if (!placed[i] && net->layers[i].kind != LK_SOFTMAX) { sid[i] = net->layers[i].side == 2 ? 1 : -1; order.push_back(i); placed[i] = 1; }
+        for (int i = 0; i < nl; ++i)
+            if (!placed[i]) order.push_back(i);
+    } else {
+        for (int i = 0; i < nl; ++i) order.push_back(i);
+    }
+    auto stream_of = [&](int i) { return sid[i] < 0 ? st : net->side[sid[i]]; };
+    auto producer_of = [&](int i, int tensor) {
+        for (int j = i - 1; j >= 0; --j)
+            if (net->layers[j].out == tensor && layer_runs(*net, net->layers[j])) return j;
+        return -1;
+    };
+    // a layer publishes its completion (ev_ready on ITS stream) when a consumer runs on another stream
+    std::vector<char> publishes(nl, 0);
+    if (overlap)
+        for (int i = 0; i < nl; ++i) {
+            const Layer& l = net->layers[i];
+            if (!layer_runs(*net, l)) continue;
+            for (int tensor : {l.in, l.res}) {
+                if (tensor < 0) continue;
+                const int pr = producer_of(i, tensor);
+                if (pr >= 0 && sid[pr] != sid[i]) publishes[pr] = 1;
+            }
+        }
     bool side_used[ssd_net::kSides] = {false, false};
     auto join_sides = [&]() -> int {
         for (int k = 0; k < ssd_net::kSides; ++k)
@@ -1011,80 +1099,33 @@ static int forward_impl(ssd_net* net, const float* image_dev, int B, float* delt
             }
         return SSD_OK;
     };
-    // Issue order (matters under hipGraph replay: the executor starts ready nodes in capture order).
-    // Every kernel of the heavy part of the graph fills the whole GPU, so overlapping two of them only
-    // splits the machine (measured: head 1 beside block_13's depthwise+project -> 239 + 212 us instead
-    // of 187 + 37).  What CAN hide is the latency-bound tail (extras 2-4, heads 3-6: ~150 us of 5-20 us
-    // kernels): the two big head convs (side stream 1) are therefore issued when the first small head
-    // (side stream 2) is, i.e. behind the last heavy main-chain layer, and run beside that tail; the
-    // small heads are issued right behind their producers.
-    std::vector<size_t> order;
-    order.reserve(net->layers.size());
-    if (overlap) {
-        std::vector<char> placed(net->layers.size(), 0);
-        std::vector<size_t> pending_big;
-        auto place_consumers = [&](int out_tensor) {
-            for (size_t j = 0; j < net->layers.size(); ++j) {
-                const Layer& c = net->layers[j];
-                if (placed[j] || !c.side || c.in != out_tensor || !layer_runs(*net, c)) continue;
-                placed[j] = 1;
-                if (c.side == 1) { pending_big.push_back(j); continue; }
-                for (size_t b : pending_big) order.push_back(b);
-                pending_big.clear();
-                order.push_back(j);
-            }
-        };
-        for (size_t i = 0; i < net->layers.size(); ++i) {
-            if (placed[i]) continue;
-            const Layer& l = net->layers[i];
-            if (l.side && layer_runs(*net, l)) continue;  // placed behind its producer
-            if (l.kind == LK_SOFTMAX) continue;           // the join point goes last
-            order.push_back(i);
-            placed[i] = 1;
-            if (l.out > 0 && layer_runs(*net, l)) place_consumers(l.out);
-        }
-        for (size_t b : pending_big) order.push_back(b);
-        for (size_t i = 0; i < net->layers.size(); ++i)
-            if (!placed[i] && net->layers[i].kind != LK_SOFTMAX) { order.push_back(i); placed[i] = 1; }
-        for (size_t i = 0; i < net->layers.size(); ++i)
-            if (!placed[i]) order.push_back(i);
-    } else {
-        for (size_t i = 0; i < net->layers.size(); ++i) order.push_back(i);
-    }
     for (size_t oi = 0; oi < order.size(); ++oi) {
-        const size_t i = order[oi];
+        const int i = (int)order[oi];
         Layer& l = net->layers[i];
         if (layer_runs(*net, l)) {
-            if (overlap && l.side) {
-                const int k = l.side - 1;
-                hipStream_t ss = net->side[k];
-                // fork: the producer of this layer's input recorded ev_ready on the main stream
-                int prod = -1;
-                for (int j = (int)i - 1; j >= 0; --j)
-                    if (net->layers[j].out == l.in && layer_runs(*net, net->layers[j])) { prod = j; break; }
-                if (prod >= 0) SSD_HIP(hipStreamWaitEvent(ss, net->layers[prod].ev_ready, 0));
-                else {      // input produced before any layer (the image): order after current main work
-                    SSD_HIP(hipEventRecord(l.ev_ready, st));
-                    SSD_HIP(hipStreamWaitEvent(ss, l.ev_ready, 0));
-                }
-                const int rc = run_layer(*net, l, B, deltas_out, probs_out, ss);
-                if (rc) return rc;
-                side_used[k] = true;
-            } else {
+            hipStream_t ls = stream_of(i);
+            if (overlap) {
                 if (l.kind == LK_SOFTMAX) {        // join before the softmax
                     const int rcj = join_sides();
                     if (rcj) return rcj;
                 }
-                const int rc = run_layer(*net, l, B, deltas_out, probs_out, st);
-                if (rc) return rc;
-                if (overlap) {
-                    // publish completion if some later side layer consumes this output
-                    bool feeds_side = false;
-                    for (size_t j = i + 1; j < net->layers.size() && !feeds_side; ++j)
-                        feeds_side = net->layers[j].side && net->layers[j].in == l.out && l.out >= 0;
-                    if (feeds_side) SSD_HIP(hipEventRecord(l.ev_ready, st));
+                bool forked = false;
+                for (int tensor : {l.in, l.res}) {
+                    if (tensor < 0) continue;
+                    const int pr = producer_of(i, tensor);
+                    if (pr >= 0 && sid[pr] != sid[i]) { SSD_HIP(hipStreamWaitEvent(ls, net->layers[pr].ev_ready, 0)); forked = true; }
                 }
+                if (sid[i] >= 0 && !side_used[sid[i]] && !forked) {
+                    // first work of a side stream whose input is not produced by a layer (the image):
+                    // order it after the current main-stream work
+                    SSD_HIP(hipEventRecord(l.ev_ready, st));
+                    SSD_HIP(hipStreamWaitEvent(ls, l.ev_ready, 0));
+                }
+                if (sid[i] >= 0) side_used[sid[i]] = true;
             }
+            const int rc = run_layer(*net, l, B, deltas_out, probs_out, ls);
+            if (rc) return rc;
+            if (overlap && publishes[i]) SSD_HIP(hipEventRecord(l.ev_ready, ls));
         }
         if (ev) (void)hipEventRecord((*ev)[i + 1], st);
     }
