@@ -86,6 +86,43 @@ def test_hyper_params_semantics():
     assert io_utils.get_log_path("vgg16").startswith("logs/vgg16/")
 
 
+def test_host_logic_vs_executed_reference(tmp_path, monkeypatch):
+    """H1 / E1 host logic against outputs of the REFERENCE's own functions (tests/golden/host_logic.json,
+    written by make_host_golden.py, which executes the reference's TF-free definitions via ast)."""
+    import copy, json
+    from utils import train_utils, io_utils
+    g = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "host_logic.json")))
+    pristine = copy.deepcopy(train_utils.SSD)
+    try:
+        for case in g["get_hyper_params"]:
+            train_utils.SSD.clear()
+            train_utils.SSD.update(copy.deepcopy(pristine))
+            out = train_utils.get_hyper_params(case["backbone"], **case["kwargs"])
+            assert out == case["out"], case
+            assert list(out) == list(case["out"]) or sorted(out) == sorted(case["out"])
+        train_utils.SSD.clear()
+        train_utils.SSD.update(copy.deepcopy(pristine))
+        train_utils.get_hyper_params("mobilenet_v2", img_size=512)
+        assert train_utils.get_hyper_params("mobilenet_v2") == g["sticky_img_size_after_override"]
+    finally:
+        train_utils.SSD.clear()
+        train_utils.SSD.update(pristine)
+    for e, lr in g["scheduler"]:
+        assert train_utils.scheduler(e) == lr, e
+    for t, b, n in g["get_step_size"]:
+        assert train_utils.get_step_size(t, b) == n
+    monkeypatch.chdir(tmp_path)
+    for m, path in g["get_model_path"].items():
+        assert io_utils.get_model_path(m) == path
+    assert os.path.isdir(tmp_path / "trained") == g["get_model_path_creates_dir"]
+    for b, ok in g["is_valid_backbone"].items():
+        if ok:
+            io_utils.is_valid_backbone(b)
+        else:
+            with pytest.raises(AssertionError):
+                io_utils.is_valid_backbone(b)
+
+
 def test_shard_range():
     import parallel
     for n in (0, 1, 7, 64, 4952):
