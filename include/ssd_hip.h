@@ -277,7 +277,8 @@ double ssd_net_layer_executed_flops(const ssd_net* net, int i, int B);
  * 7-12 / 14-16: expand -> depthwise -> project with the expanded map kept on the CU) replace expand
  * GEMM + depthwise/project where it won finalize's on-device race, 2 forces it wherever it applies,
  * 0 disables it; "image_ticket" (default 0) makes that kernel combine its channel-group partial sums
- * inside the launch (arrival ticket, last arriver) instead of by a second launch; "overlap_heads" (default 1) runs the SSD head convs on a side stream; "use_wino" (default 1)
+ * inside the launch (arrival ticket, last arriver) instead of by a second launch; "overlap_heads" (default 1) runs the SSD head convs on side streams ("tail_on_side", default 0,
+ * swaps the roles: big head convs on the caller's stream, the small tail layers on the side streams -- measured slower); "use_wino" (default 1)
  * offers the Winograd F(2x2,3x3) kernels to finalize's autotune for the 3x3 stride-1 convs. */
 int ssd_net_set_option(ssd_net* net, const char* name, int value);
 /* Diagnostics: per-phase mean cycles per wave of one fused block layer (clock64 inside the

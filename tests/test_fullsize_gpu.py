@@ -218,6 +218,41 @@ def test_decoder_c5_shard_24564_anchors():
     _check_nms_contract(_np(b), _np(l), _np(s), L)
 
 
+@pytest.mark.parametrize("backbone", ["mobilenet_v2", "vgg16"])
+def test_stream_plans_agree(backbone):
+    """forward_impl's per-layer stream plan: heads overlapped on side streams (default), the swapped
+    roles (tail_on_side), no overlap, graph replay on and off -- all the same kernels in another
+    order, so the outputs are bitwise identical."""
+    from models.decoder import get_decoder_model
+    from utils import bbox_utils
+    if backbone == "mobilenet_v2":
+        from models.ssd_mobilenet_v2 import get_model
+    else:
+        from models.ssd_vgg16 import get_model
+    hp = helpers.hyper_params(backbone)
+    w = helpers.synthetic_weights(backbone, hp)
+    m = get_model(hp, max_batch=6)
+    m.set_weights(w)
+    priors = bbox_utils.generate_prior_boxes(hp["feature_map_shapes"], hp["aspect_ratios"])
+    dm = get_decoder_model(m, priors, hp)
+    x = helpers.images(6, 300, seed=4)
+    ref = None
+    for opts in ({"overlap_heads": 1, "tail_on_side": 0, "use_graph": 1}, {"overlap_heads": 1, "tail_on_side": 1, "use_graph": 1},
+                 {"overlap_heads": 1, "tail_on_side": 1, "use_graph": 0}, {"overlap_heads": 0, "tail_on_side": 0, "use_graph": 0},
+                 {"overlap_heads": 1, "tail_on_side": 0, "use_graph": 0}):
+        for k, v in opts.items():
+            m.set_option(k, v)
+        outs = []
+        for rep in range(3):                      # eager first call, capture, replay
+            outs.append([r.copy() for r in dm.predict_on_batch(x)])
+        if ref is None:
+            ref = outs[0]
+            assert (ref[2] > 0).sum() > 0
+        for o in outs:
+            for a, b in zip(o, ref):
+                np.testing.assert_array_equal(a, b, err_msg=str(opts))
+
+
 def test_predict_ascending_batch_sizes():
     """ssd_net_predict's head-output scratch must follow a re-finalize with a larger max_batch
     (B=1 then B=8 on the same model used to overflow the B=1-sized buffers), and the captured

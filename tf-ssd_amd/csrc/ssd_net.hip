@@ -1009,13 +1009,14 @@ static int forward_impl(ssd_net* net, const float* image_dev, int B, float* delt
     //   side[0]     : the two big head convs (side == 1), captured right behind feature map 3's producer
     //                 (launching their split-K reduces behind BOTH of them instead of in between: no change)
     //   side[1]     : the small heads (side == 2), each right behind its producer
-    // SSD_TAIL_ON_SIDE=1 swaps the roles (big heads back to back on the main stream, the tail on the
+    // SSD_TAIL_ON_SIDE=1 / option "tail_on_side" swaps the roles (big heads back to back on the main stream, the tail on the
     // side streams): measured 2.07 instead of 1.99 ms -- beside a head conv whose workgroups hold every
     // CU's LDS / VGPRs a 10 us tail kernel waits for retiring workgroups (120-150 us each), and the
     // dependent tail chain then outlives the heads.  In the shipped plan the executor starts head 1
     // ~80 us after the backbone, i.e. the first third of the tail runs alone and un-starved.
     const int nl = (int)net->layers.size();
-    static const bool tail_on_side = getenv("SSD_TAIL_ON_SIDE") ? atoi(getenv("SSD_TAIL_ON_SIDE")) != 0 : false;
+    static const bool tail_env = getenv("SSD_TAIL_ON_SIDE") ? atoi(getenv("SSD_TAIL_ON_SIDE")) != 0 : false;
+    const bool tail_on_side = tail_env || net->tail_on_side;
     std::vector<int> sid(nl, -1);           // -1 main, 0 / 1 side stream
     std::vector<size_t> order;
     order.reserve(nl);
@@ -1267,6 +1268,11 @@ int ssd_net_set_option(ssd_net* net, const char* name, int value) {
     }
     if (std::string(name) == "fuse_image") {
         net->fuse_image = value < 0 ? 0 : (value > 2 ? 2 : value);
+        net->drop_graphs();
+        return SSD_OK;
+    }
+    if (std::string(name) == "tail_on_side") {
+        net->tail_on_side = value != 0;
         net->drop_graphs();
         return SSD_OK;
     }
