@@ -150,7 +150,7 @@ __global__ __launch_bounds__(256) void dilate2_kernel(const float* __restrict__ 
 
 // ------------------------------------------------------------------ column reductions over [M][C]
 // block = 64 columns x 4 row lanes; grid = (ceil(C/64), chunks); partial[chunk][2][C].
-enum { RED_SUM = 0, RED_SQDEV = 1, RED_BN_BWD = 2, RED_ACT_BWD = 3 };
+enum { RED_SUM = 0, RED_SQDEV = 1, RED_BN_BWD = 2, RED_ACT_BWD = 3, RED_STATS = 4 };
 struct RedParams {
     const float* a;       // SUM/SQDEV: x;  BN_BWD / ACT_BWD: dout
     const float* b;       // BN_BWD: pre;   ACT_BWD: out (nullable: no activation)
@@ -203,10 +203,77 @@ __global__ __launch_bounds__(256) void col_reduce_kernel(const RedParams p) {
         p.partial[o + p.C + c] = t2;
     }
 }
-// out1[c] = scale * sum_chunks partial[.][0][c]; out2 likewise (nullable); mode 1: out2 = rsqrt(out1 + eps)
+
+// 16-byte form of col_reduce_kernel for C % 4 == 0 (every tensor of both graphs): thread = 4
+// consecutive channels; block = CQ channel quads x (256 / CQ) row lanes.  RED_STATS: one pass for
+// the batch statistics -- sums of (x - K) and (x - K)^2 with the per-column shift K = x[0][c] common to
+// every chunk (a sample of the column, so (mean - K)^2 ~ var: no cancellation in s2/M - (s1/M)^2).
+typedef float tf32x4 __attribute__((ext_vector_type(4)));
+template <int OP>
+__global__ __launch_bounds__(256) void col_reduce4_kernel(const RedParams p) {
+    __shared__ tf32x4 sh[2][256];
+    const int CQ = p.cw, RL = 256 / CQ;
+    const int cl = threadIdx.x % CQ, rl = threadIdx.x / CQ;
+    const int c = (blockIdx.x * CQ + cl) * 4;
+    const long r0 = (long)blockIdx.y * p.rows_per_chunk;
+    const long r1 = r0 + p.rows_per_chunk < p.M ? r0 + p.rows_per_chunk : p.M;
+    tf32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = {0.f, 0.f, 0.f, 0.f};
+    if (c < p.C) {
+        tf32x4 mean = s1, istd = s1, gamma = s1, beta = s1;
+        if (OP == RED_SQDEV || OP == RED_BN_BWD) mean = *reinterpret_cast<const tf32x4*>(p.mean + c);
+        if (OP == RED_STATS) mean = *reinterpret_cast<const tf32x4*>(p.a + c);          // the shift K
+        if (OP == RED_BN_BWD) {
+            istd = *reinterpret_cast<const tf32x4*>(p.istd + c);
+            gamma = *reinterpret_cast<const tf32x4*>(p.gamma + c);
+            beta = *reinterpret_cast<const tf32x4*>(p.beta + c);
+        }
+#pragma unroll 4
+        for (long r = r0 + rl; r < r1; r += RL) {
+            const tf32x4 a = *reinterpret_cast<const tf32x4*>(p.a + r * p.lda + c);
+            if (OP == RED_SUM) s1 += a;
+            else if (OP == RED_SQDEV) { const tf32x4 d = a - mean; s1 += d * d; }
+            else if (OP == RED_STATS) { const tf32x4 d = a - mean; s1 += d; s2 += d * d; }
+            else if (OP == RED_BN_BWD) {
+                const tf32x4 xh = (*reinterpret_cast<const tf32x4*>(p.b + r * p.C + c) - mean) * istd;
+                const tf32x4 z = xh * gamma + beta;
+                tf32x4 dz;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) dz[j] = a[j] * act_mask(z[j], p.act);
+                s1 += dz;
+                s2 += dz * xh;
+            } else {
+                if (p.b) {
+                    const tf32x4 o = *reinterpret_cast<const tf32x4*>(p.b + r * p.C + c);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) s1[j] += a[j] * act_mask(o[j], p.act);
+                } else {
+                    s1 += a;
+                }
+            }
+        }
+    }
+    sh[0][threadIdx.x] = s1;
+    sh[1][threadIdx.x] = s2;
+    __syncthreads();
+    if (rl == 0 && c < p.C) {
+        tf32x4 t1 = {0.f, 0.f, 0.f, 0.f}, t2 = {0.f, 0.f, 0.f, 0.f};
+        for (int k = 0; k < RL; ++k) {           // fixed order: deterministic
+            t1 += sh[0][k * CQ + cl];
+            t2 += sh[1][k * CQ + cl];
+        }
+        const long o = (long)blockIdx.y * 2 * p.C;
+        *reinterpret_cast<tf32x4*>(p.partial + o + c) = t1;
+        *reinterpret_cast<tf32x4*>(p.partial + o + p.C + c) = t2;
+    }
+}
+// out1[c] = scale * sum_chunks partial[.][0][c]; out2 likewise (nullable); mode 1: out2 = rsqrt(out1 + eps);
+// mode 2 (batch statistics from RED_STATS partials, shift row `shift`): out1 = mean, out2 = biased variance,
+// out3 = rsqrt(var + eps), and the Keras moving averages mm / mv move towards them
 __global__ __launch_bounds__(256) void col_finalize_kernel(const float* __restrict__ partial, const int chunks, const int C,
                                                           const float scale, float* out1, float* out2, const int mode,
-                                                          const float eps) {
+                                                          const float eps, const float* shift = nullptr, float* out3 = nullptr,
+                                                          float* mm = nullptr, float* mv = nullptr,
+                                                          const float one_minus_momentum = 0.f) {
     // block = 16 columns x 16 chunk lanes (lane k sums chunks k, k+16, ... in order; the 16 lane
     // sums are combined in a fixed order: deterministic).  The data is tiny; the kernel is latency
     // bound, hence many short dependent chains instead of few long ones.
@@ -230,6 +297,16 @@ __global__ __launch_bounds__(256) void col_finalize_kernel(const float* __restri
     }
     s1 *= scale;
     s2 *= scale;
+    if (mode == 2) {
+        const float mean = shift[c] + s1;
+        const float var = fmaxf(s2 - s1 * s1, 0.0f);
+        out1[c] = mean;
+        out2[c] = var;
+        out3[c] = 1.0f / sqrtf(var + eps);
+        mm[c] -= (mm[c] - mean) * one_minus_momentum;       // Keras moving average: v -= (v - value) * (1 - momentum)
+        mv[c] -= (mv[c] - var) * one_minus_momentum;
+        return;
+    }
     if (out1) out1[c] = s1;
     if (mode == 1) out2[c] = 1.0f / sqrtf(s1 + eps);
     else if (out2) out2[c] = s2;
@@ -621,6 +698,24 @@ static int ensure_partial(ssd_train_state& s, size_t floats) {
 
 template <int OP>
 static int col_reduce(ssd_train_state& s, RedParams p, long* chunks_out, hipStream_t st) {
+    const bool vec = p.C % 4 == 0 && p.lda % 4 == 0 && (((uintptr_t)p.a | (uintptr_t)p.b) & 15) == 0;
+    if (vec) {
+        // channel quads per block: a power of two <= 64 that wastes few lanes (C / 4 = 4 .. 320)
+        const int q = p.C / 4;
+        p.cw = q % 64 == 0 ? 64 : (q % 32 == 0 ? 32 : (q % 16 == 0 ? 16 : (q % 8 == 0 ? 8 : (q < 8 ? 4 : (q < 48 ? 16 : 64)))));
+        const int ctiles = (q + p.cw - 1) / p.cw;
+        long rpc = 0;
+        const long chunks = chunks_for(p.M, ctiles, &rpc, 64, 256);
+        int rc = ensure_partial(s, (size_t)chunks * 2 * p.C);
+        if (rc) return rc;
+        p.rows_per_chunk = rpc;
+        p.partial = s.partial;
+        hipLaunchKernelGGL(col_reduce4_kernel<OP>, dim3(ctiles, (unsigned)chunks), dim3(256), 0, st, p);
+        SSD_LAUNCH_CHECK();
+        *chunks_out = chunks;
+        return SSD_OK;
+    }
+    SSD_UNSUPPORTED_IF(OP == RED_STATS, "train: batch statistics need C %% 4 == 0 (C = %d)", p.C);
     p.cw = p.C % 64 == 0 ? 64 : (p.C % 32 == 0 ? 32 : (p.C % 16 == 0 ? 16 : (p.C < 64 ? 32 : 64)));
     const int ctiles = (p.C + p.cw - 1) / p.cw;
     long rpc = 0;
@@ -642,18 +737,33 @@ static int col_finalize(ssd_train_state& s, long chunks, int C, float scale, flo
     return SSD_OK;
 }
 
-// two-pass batch statistics of pre [M][C] -> mean, var (biased), istd
-static int bn_stats(ssd_train_state& s, TrainLayer& t, long M, int C, hipStream_t st) {
+// batch statistics of pre [M][C] -> mean, var (biased), istd, and the moving-average update: one
+// pass over `pre` (shifted sums, see col_reduce4_kernel) + one finalize launch
+static int bn_stats(ssd_train_state& s, TrainLayer& t, long M, int C, float* moving_mean, float* moving_var,
+                    hipStream_t st) {
     RedParams p{};
     p.a = t.pre; p.M = M; p.C = C; p.lda = C;
     long chunks = 0;
+    if (C % 4 == 0 && ((uintptr_t)t.pre & 15) == 0) {
+        int rc = col_reduce<RED_STATS>(s, p, &chunks, st);
+        if (rc) return rc;
+        hipLaunchKernelGGL(col_finalize_kernel, dim3((C + 15) / 16), dim3(256), 0, st, s.partial, (int)chunks, C,
+                           1.0f / (float)M, t.mean, t.var, 2, kBnEps, t.pre, t.istd, moving_mean, moving_var,
+                           1.0f - kBnMomentum);
+        SSD_LAUNCH_CHECK();
+        return SSD_OK;
+    }
     int rc = col_reduce<RED_SUM>(s, p, &chunks, st);
     if (!rc) rc = col_finalize(s, chunks, C, 1.0f / (float)M, t.mean, nullptr, 0, st);
     if (rc) return rc;
     p.mean = t.mean;
     rc = col_reduce<RED_SQDEV>(s, p, &chunks, st);
     if (!rc) rc = col_finalize(s, chunks, C, 1.0f / (float)M, t.var, t.istd, 1, st);
-    return rc;
+    if (rc) return rc;
+    hipLaunchKernelGGL(moving_update_kernel, dim3((C + 255) / 256), dim3(256), 0, st, moving_mean, moving_var, t.mean, t.var, C,
+                       1.0f - kBnMomentum);
+    SSD_LAUNCH_CHECK();
+    return SSD_OK;
 }
 
 static ConvParams dense_conv_params(int B, int H, int W, int Cin, int Cout, int kh, int kw, int stride, int dil,
@@ -974,11 +1084,8 @@ int ssd_net_train_forward_backward(ssd_net* net, const float* image_dev, int B, 
             if (rc) return rc;
         }
         if (l.p_bn >= 0) {
-            rc = bn_stats(s, t, M, l.Cout, st);
+            rc = bn_stats(s, t, M, l.Cout, net->params[l.p_bn + 2].dev, net->params[l.p_bn + 3].dev, st);
             if (rc) return rc;
-            hipLaunchKernelGGL(moving_update_kernel, dim3((l.Cout + 255) / 256), dim3(256), 0, st,
-                               net->params[l.p_bn + 2].dev, net->params[l.p_bn + 3].dev, t.mean, t.var, l.Cout,
-                               1.0f - kBnMomentum);
             hipLaunchKernelGGL(bn_apply_kernel, dim3(grid_for(M * l.Cout)), dim3(256), 0, st, t.pre, M, l.Cout, t.mean,
                                t.istd, net->params[l.p_bn].dev, net->params[l.p_bn + 1].dev, l.act,
                                l.res >= 0 ? s.act[l.res] : nullptr, s.act[l.out]);
