@@ -120,6 +120,39 @@ __global__ __launch_bounds__(256) void rot_transpose_kernel(const float* __restr
     }
 }
 
+// Every weight re-pack of a training step as ONE launch (the weights change every step; 103 forward
+// packs + 54 rotate/transposes + 50 backward packs were 0.75 ms of 5 us launches): blockIdx.y = job.
+//   mode 0  forward:        dst[n][k] = W[k][n]                          ([Npad][Kpad], zero padded;
+//           a head conv's label (w, Cout1 columns) and box (w2) kernels are stacked along n)
+//   mode 1  backward-data:  dst[ci][(ky', kx', co')] = W[kh-1-ky'][kw-1-kx'][ci][co']   (rotated and
+//           transposed: the forward conv kernel then computes dX from dY; co' < CoPad, zero padded)
+struct PackJob {
+    const float* w;
+    const float* w2;
+    float* dst;
+    int mode, K, Cout, Cout1, Kpad, Npad, kh, kw, Ci, CoPad;
+};
+__global__ __launch_bounds__(256) void pack_jobs_kernel(const PackJob* __restrict__ jobs) {
+    const PackJob j = jobs[blockIdx.y];
+    const long total = (long)j.Npad * j.Kpad;
+    const int C2 = j.Cout - j.Cout1;
+    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+        const int n = (int)(e / j.Kpad), k = (int)(e - (long)n * j.Kpad);
+        float v = 0.f;
+        if (j.mode == 0) {
+            if (n < j.Cout && k < j.K) v = n < j.Cout1 ? j.w[(long)k * j.Cout1 + n] : j.w2[(long)k * C2 + (n - j.Cout1)];
+        } else if (n < j.Ci && k < j.kh * j.kw * j.CoPad) {
+            const int co = k % j.CoPad, tap = k / j.CoPad;
+            if (co < j.Cout) {
+                const int ky = j.kh - 1 - tap / j.kw, kx = j.kw - 1 - tap % j.kw;
+                const long row = (long)(ky * j.kw + kx) * j.Ci + n;
+                v = co < j.Cout1 ? j.w[row * j.Cout1 + co] : j.w2[row * C2 + (co - j.Cout1)];
+            }
+        }
+        j.dst[e] = v;
+    }
+}
+
 // dense[b][p][c] (row stride ld) = src[b * bs + off + p * ps + c]   (one head level out of the
 // concatenated [B,N,K] gradient buffer); col0 = first dense column written
 __global__ __launch_bounds__(256) void gather_head_kernel(const float* __restrict__ src, const long bs, const long off,
@@ -327,6 +360,43 @@ __global__ __launch_bounds__(256) void chunk_sum_kernel(const float* __restrict_
         __syncthreads();
         if (kl == 0 && e < n) out[e] = (sh[0][el] + sh[1][el]) + (sh[2][el] + sh[3][el]);
     }
+}
+
+// 16-byte form for n % 4 == 0: block = EQ element quads x (256 / EQ) chunk lanes (lane k sums chunks
+// k, k + KL, ... in order, then the KL lane sums in a fixed order: deterministic).  Small outputs
+// (a 96 x 24 pointwise kernel summed over 1024 M-chunks) get EQ = 4: 16 elements per block, 64
+// chunk lanes -- the 64-element / 4-lane form left such layers with 36 blocks walking 256 chunks each.
+template <int EQ>
+__global__ __launch_bounds__(256) void chunk_sum4_kernel(const float* __restrict__ partial, const int chunks,
+                                                        const long n, float* __restrict__ out, const int aligned_out) {
+    constexpr int KL = 256 / EQ;
+    __shared__ tf32x4 sh[KL][EQ];
+    const int el = threadIdx.x % EQ, kl = threadIdx.x / EQ;
+    const long e = ((long)blockIdx.x * EQ + el) * 4;
+    tf32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    if (e < n)
+        for (int k = kl; k < chunks; k += KL) acc += *reinterpret_cast<const tf32x4*>(partial + (long)k * n + e);
+    sh[kl][el] = acc;
+    __syncthreads();
+    if (kl != 0 || e >= n) return;
+    tf32x4 t = sh[0][el];
+    for (int k = 1; k < KL; ++k) t += sh[k][el];
+    if (aligned_out) *reinterpret_cast<tf32x4*>(out + e) = t;
+    else
+        for (int j = 0; j < 4; ++j) out[e + j] = t[j];
+}
+static int chunk_sum(const float* partial, long chunks, long n, float* out, hipStream_t st) {
+    if (n % 4 == 0 && ((uintptr_t)partial & 15) == 0) {
+        const int aligned = ((uintptr_t)out & 15) == 0;
+        if (n < 65536) hipLaunchKernelGGL(chunk_sum4_kernel<4>, dim3((unsigned)((n / 4 + 3) / 4)), dim3(256), 0, st, partial, (int)chunks, n, out, aligned);
+        else hipLaunchKernelGGL(chunk_sum4_kernel<16>, dim3((unsigned)((n / 4 + 15) / 16)), dim3(256), 0, st, partial, (int)chunks, n, out, aligned);
+    } else {
+        const long b = (n * 4 + 255) / 256;
+        hipLaunchKernelGGL(chunk_sum_kernel, dim3((unsigned)(b < 1 ? 1 : (b > 16384 ? 16384 : b))), dim3(256), 0, st, partial,
+                           (int)chunks, n, out);
+    }
+    SSD_LAUNCH_CHECK();
+    return SSD_OK;
 }
 
 // ------------------------------------------------------------------ conv backward-weights (MFMA)
@@ -639,6 +709,8 @@ struct ssd_train_state {
     std::vector<TrainLayer> tl;
     std::vector<float*> owned;
     float *scratch_dy = nullptr, *scratch_dz = nullptr, *scratch_w = nullptr, *partial = nullptr;
+    float* pack_jobs = nullptr;  // device array of PackJob (one launch re-packs every conv weight)
+    int n_pack_jobs = 0;
     size_t partial_floats = 0;
     float *dgamma_tmp = nullptr, *dbeta_tmp = nullptr;
     float *deltas = nullptr, *probs = nullptr, *gdeltas = nullptr, *glogits = nullptr;
@@ -816,9 +888,7 @@ static int wgrad(ssd_train_state& s, const Layer& l, int B, const float* x, cons
     p.partial = s.partial;
     hipLaunchKernelGGL(wgrad_mfma_kernel, dim3((unsigned)tiles, (unsigned)chunks), dim3(256), 0, st, p);
     SSD_LAUNCH_CHECK();
-    hipLaunchKernelGGL(chunk_sum_kernel, dim3(grid_for((long)kn * 4)), dim3(256), 0, st, s.partial, (int)chunks, (long)kn, dW);
-    SSD_LAUNCH_CHECK();
-    return SSD_OK;
+    return chunk_sum(s.partial, chunks, (long)kn, dW, st);
 }
 
 }  // namespace ssd
@@ -929,6 +999,29 @@ int ssd_net_train_begin(ssd_net* net, int batch) {
             max_out = std::max(max_out, mc);
         }
     }
+    // one PackJob per forward / backward-data weight matrix (the parameters will live at flat + poff)
+    std::vector<PackJob> jobs;
+    for (size_t i = 0; i < net->layers.size() && !rc; ++i) {
+        const Layer& l = net->layers[i];
+        const TrainLayer& t = s->tl[i];
+        if (!t.active || l.kind != LK_CONV) continue;
+        PackJob j{};
+        j.w = s->flat + s->poff[l.p_kernel];
+        j.w2 = l.p_kernel2 >= 0 ? s->flat + s->poff[l.p_kernel2] : nullptr;
+        j.K = l.kh * l.kw * l.Cin;
+        j.Cout = l.Cout;
+        j.Cout1 = l.p_kernel2 >= 0 ? l.Cout1 : l.Cout;
+        j.kh = l.kh; j.kw = l.kw; j.Ci = l.Cin; j.CoPad = t.cpad;
+        j.mode = 0; j.dst = t.wfwd; j.Kpad = conv_kpad(j.K); j.Npad = conv_npad(l.Cout);
+        jobs.push_back(j);
+        if (t.wbwd) {
+            const int Kb = l.kh * l.kw * t.cpad;
+            j.mode = 1; j.dst = t.wbwd; j.Kpad = conv_kpad(Kb); j.Npad = conv_npad(l.Cin);
+            jobs.push_back(j);
+        }
+    }
+    s->n_pack_jobs = (int)jobs.size();
+    if (!rc && !jobs.empty()) rc = talloc(*s, (jobs.size() * sizeof(PackJob) + 3) / 4, &s->pack_jobs);
     if (!rc) rc = talloc(*s, max_out, &s->scratch_dy);
     if (!rc) rc = talloc(*s, max_dz, &s->scratch_dz);
     if (!rc) rc = talloc(*s, max_w, &s->scratch_w);
@@ -969,6 +1062,8 @@ int ssd_net_train_begin(ssd_net* net, int batch) {
             off += (long)net->params[i].count;
         }
     }
+    if (s->n_pack_jobs)
+        copy_failed |= hipMemcpy(s->pack_jobs, jobs.data(), jobs.size() * sizeof(PackJob), hipMemcpyHostToDevice) != hipSuccess;
     if (copy_failed) {
         set_error("ssd_net_train_begin: device copy failed");
         ssd_train_state_free(s);
@@ -1004,6 +1099,12 @@ int ssd_net_train_forward_backward(ssd_net* net, const float* image_dev, int B, 
     s.act[0] = const_cast<float*>(image_dev);
     int rc = SSD_OK;
 
+    // re-pack the (just updated) weights of every conv: forward and backward-data forms, one launch
+    if (s.n_pack_jobs) {
+        hipLaunchKernelGGL(pack_jobs_kernel, dim3(16, (unsigned)s.n_pack_jobs), dim3(256), 0, st,
+                           reinterpret_cast<const PackJob*>(s.pack_jobs));
+        SSD_LAUNCH_CHECK();
+    }
     // ------------------------------------------------------------ forward (training mode)
     for (size_t i = 0; i < net->layers.size(); ++i) {
         const Layer& l = net->layers[i];
@@ -1022,32 +1123,6 @@ int ssd_net_train_forward_backward(ssd_net* net, const float* image_dev, int B, 
             continue;
         }
         if (l.kind == LK_CONV) {
-            const int K = l.kh * l.kw * l.Cin;
-            // re-pack the (just updated) weights: forward and backward-data forms
-            if (l.p_kernel2 < 0) {
-                rc = launch_pack_weights(net->params[l.p_kernel].dev, K, l.Cout, conv_kpad(K), conv_npad(l.Cout), t.wfwd, st);
-            } else {
-                SSD_HIP(hipMemsetAsync(t.wfwd, 0, (size_t)conv_kpad(K) * conv_npad(l.Cout) * sizeof(float), st));
-                rc = launch_pack_weights(net->params[l.p_kernel].dev, K, l.Cout1, conv_kpad(K), l.Cout1, t.wfwd, st);
-                if (!rc) rc = launch_pack_weights(net->params[l.p_kernel2].dev, K, l.Cout - l.Cout1, conv_kpad(K),
-                                                  l.Cout - l.Cout1, t.wfwd + (size_t)l.Cout1 * conv_kpad(K), st);
-            }
-            if (rc) return rc;
-            if (t.wbwd) {
-                const size_t nw = (size_t)l.kh * l.kw * t.cpad * l.Cin;
-                if (t.cpad != l.Cout) SSD_HIP(hipMemsetAsync(s.scratch_w, 0, nw * sizeof(float), st));
-                hipLaunchKernelGGL(rot_transpose_kernel, dim3(grid_for((long)K * l.Cout)), dim3(256), 0, st,
-                                   net->params[l.p_kernel].dev, l.kh, l.kw, l.Cin, l.p_kernel2 >= 0 ? l.Cout1 : l.Cout,
-                                   t.cpad, 0, s.scratch_w);
-                if (l.p_kernel2 >= 0)
-                    hipLaunchKernelGGL(rot_transpose_kernel, dim3(grid_for((long)K * (l.Cout - l.Cout1))), dim3(256), 0, st,
-                                       net->params[l.p_kernel2].dev, l.kh, l.kw, l.Cin, l.Cout - l.Cout1, t.cpad, l.Cout1,
-                                       s.scratch_w);
-                SSD_LAUNCH_CHECK();
-                const int Kb = l.kh * l.kw * t.cpad;
-                rc = launch_pack_weights(s.scratch_w, Kb, l.Cin, conv_kpad(Kb), conv_npad(l.Cin), t.wbwd, st);
-                if (rc) return rc;
-            }
             ConvParams p = dense_conv_params(B, l.H, l.W, l.Cin, l.Cout, l.kh, l.kw, l.stride, l.dil, l.pt, l.pl, l.Ho, l.Wo);
             p.in = x;
             p.w = t.wfwd;
@@ -1219,8 +1294,8 @@ int ssd_net_train_forward_backward(ssd_net* net, const float* image_dev, int B, 
             dp.rows_per_chunk = rpc;
             dp.partial = s.partial;
             hipLaunchKernelGGL(dw_wgrad_kernel, dim3(ctiles, (unsigned)chunks), dim3(256), 0, st, dp);
-            hipLaunchKernelGGL(chunk_sum_kernel, dim3(grid_for(36L * l.Cin)), dim3(256), 0, st, s.partial, (int)chunks,
-                               9L * l.Cin, grads_flat_dev + t.g_kernel);
+            rc = chunk_sum(s.partial, chunks, 9L * l.Cin, grads_flat_dev + t.g_kernel, st);
+            if (rc) return rc;
             hipLaunchKernelGGL(dw_dgrad_kernel, dim3(grid_for((long)B * l.H * l.W * (l.Cin / 4))), dim3(256), 0, st, dp);
             SSD_LAUNCH_CHECK();
             s.gwritten[l.in] = 1;
