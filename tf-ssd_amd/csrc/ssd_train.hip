@@ -404,8 +404,8 @@ static int chunk_sum(const float* partial, long chunks, long n, float* out, hipS
 // tile of one tap over one M chunk; both operands are staged row-major ([m][channel], exactly as
 // they lie in HBM: coalesced 16-byte loads) into LDS with an 80-float row stride, so that the
 // MFMA fragments -- A[i][kk] = X[m0+kk][c0+i], B[kk][j] = G[m0+kk][n0+j], kk = lane/16 -- are
-// conflict-free ds_read_b32 (bank = 16*kk + lane%16).  4 waves = 2 x 2 wave tiles of 32 x 32.
-constexpr int WG_BM = 32, WG_LD = 80;
+// conflict-free ds_read_b32 (bank = 16*kk + lane%16).
+constexpr int WG_BM = 32;
 struct WgradParams {
     const float* x;
     const float* g;
@@ -416,32 +416,44 @@ struct WgradParams {
     int ctiles, ntiles;   // channel tiles per tap, n tiles
     int vec_x, vec_g;
 };
+// Tile shape = (WC x WN wave grid) x (TI x TJ 16x16 MFMA tiles per wave): TC = 16*TI*WC input channels by
+// TN = 16*TJ*WN output channels.  MobileNetV2 has many 16-32 channel sides (a 16 -> 96 expand fills 19 %
+// of a 64 x 64 tile), so the host picks per layer the shape with the least padded area.
+template <int WC, int WN_, int TI, int TJ>
 __global__ __launch_bounds__(256) void wgrad_mfma_kernel(const WgradParams p) {
-    __shared__ __attribute__((aligned(16))) float Xs[WG_BM * WG_LD];
-    __shared__ __attribute__((aligned(16))) float Gs[WG_BM * WG_LD];
+    static_assert(WC * WN_ == 4, "4 waves");
+    constexpr int TC = 16 * TI * WC, TN = 16 * TJ * WN_;
+    // row strides = 16 (mod 64) floats: the four 16-lane groups of a fragment read (rows 4s + kk) hit
+    // disjoint bank quarters
+    constexpr int LDX = (TC + 63) / 64 * 64 + 16, LDG = (TN + 63) / 64 * 64 + 16;
+    constexpr int XQ = TC / 4, GQ = TN / 4;                // float4 per row
+    constexpr int XU = WG_BM * XQ, GU = WG_BM * GQ;        // float4 units per slab
+    __shared__ __attribute__((aligned(16))) float Xs[WG_BM * LDX];
+    __shared__ __attribute__((aligned(16))) float Gs[WG_BM * LDG];
     int t = blockIdx.x;
     const int nt = t % p.ntiles;
     t /= p.ntiles;
     const int ct = t % p.ctiles, tap = t / p.ctiles;
     const int ky = tap / p.kw, kx = tap % p.kw;
-    const int c0 = ct * 64, n0 = nt * 64;
+    const int c0 = ct * TC, n0 = nt * TN;
     const long mBeg = (long)blockIdx.y * p.rows_per_chunk;
     const long mEnd = mBeg + p.rows_per_chunk < p.M ? mBeg + p.rows_per_chunk : p.M;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int wk = wv >> 1, wn = wv & 1;
-    f32x4 acc[2][2];
+    const int wk = wv / WN_, wn = wv % WN_;
+    f32x4 acc[TI][TJ];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < TI; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < TJ; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     for (long m0 = mBeg; m0 < mEnd; m0 += WG_BM) {
         __syncthreads();
 #pragma unroll
-        for (int it = 0; it < 2; ++it) {
-            const int idx = tid + it * 256;
-            const int row = idx >> 4, q = (idx & 15) * 4;
+        for (int u0 = 0; u0 < XU; u0 += 256) {
+            const int u = u0 + tid;
+            if (XU % 256 != 0 && u >= XU) break;
+            const int row = u / XQ, q = (u - row * XQ) * 4;
             const long m = m0 + row;
-            f32x4 xv = {0.f, 0.f, 0.f, 0.f}, gv = {0.f, 0.f, 0.f, 0.f};
+            f32x4 xv = {0.f, 0.f, 0.f, 0.f};
             if (m < mEnd) {
                 const int ox = (int)(m % p.Wo);
                 const long r = m / p.Wo;
@@ -455,6 +467,17 @@ __global__ __launch_bounds__(256) void wgrad_mfma_kernel(const WgradParams p) {
                         for (int j = 0; j < 4; ++j)
                             if (c0 + q + j < p.Cin) xv[j] = xp[j];
                 }
+            }
+            *reinterpret_cast<f32x4*>(&Xs[row * LDX + q]) = xv;
+        }
+#pragma unroll
+        for (int u0 = 0; u0 < GU; u0 += 256) {
+            const int u = u0 + tid;
+            if (GU % 256 != 0 && u >= GU) break;
+            const int row = u / GQ, q = (u - row * GQ) * 4;
+            const long m = m0 + row;
+            f32x4 gv = {0.f, 0.f, 0.f, 0.f};
+            if (m < mEnd) {
                 const float* gp = p.g + m * p.ldg + n0 + q;
                 if (p.vec_g && n0 + q + 3 < p.N) gv = *reinterpret_cast<const f32x4*>(gp);
                 else
@@ -462,38 +485,58 @@ __global__ __launch_bounds__(256) void wgrad_mfma_kernel(const WgradParams p) {
                     for (int j = 0; j < 4; ++j)
                         if (n0 + q + j < p.N) gv[j] = gp[j];
             }
-            *reinterpret_cast<f32x4*>(&Xs[row * WG_LD + q]) = xv;
-            *reinterpret_cast<f32x4*>(&Gs[row * WG_LD + q]) = gv;
+            *reinterpret_cast<f32x4*>(&Gs[row * LDG + q]) = gv;
         }
         __syncthreads();
         const int kk = lane >> 4, li = lane & 15;
 #pragma unroll
         for (int s = 0; s < WG_BM / 4; ++s) {
             const int r = 4 * s + kk;
-            const float a0 = Xs[r * WG_LD + wk * 32 + li], a1 = Xs[r * WG_LD + wk * 32 + 16 + li];
-            const float b0 = Gs[r * WG_LD + wn * 32 + li], b1 = Gs[r * WG_LD + wn * 32 + 16 + li];
-            acc[0][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b0, acc[0][0], 0, 0, 0);
-            acc[0][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b1, acc[0][1], 0, 0, 0);
-            acc[1][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b0, acc[1][0], 0, 0, 0);
-            acc[1][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b1, acc[1][1], 0, 0, 0);
+            float av[TI], bv[TJ];
+#pragma unroll
+            for (int i = 0; i < TI; ++i) av[i] = Xs[r * LDX + (wk * TI + i) * 16 + li];
+#pragma unroll
+            for (int j = 0; j < TJ; ++j) bv[j] = Gs[r * LDG + (wn * TJ + j) * 16 + li];
+#pragma unroll
+            for (int i = 0; i < TI; ++i)
+#pragma unroll
+                for (int j = 0; j < TJ; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i], bv[j], acc[i][j], 0, 0, 0);
         }
     }
     // lane owns D[i = 4*(lane/16) + r][j = lane%16] of each 16x16 tile
     float* out = p.partial + (long)blockIdx.y * p.K * p.N;
     const int li = lane & 15, lr = (lane >> 4) * 4;
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < TI; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int n = n0 + wn * 32 + j * 16 + li;
+        for (int j = 0; j < TJ; ++j) {
+            const int n = n0 + (wn * TJ + j) * 16 + li;
             if (n >= p.N) continue;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int ci = c0 + wk * 32 + i * 16 + lr + r;
+                const int ci = c0 + (wk * TI + i) * 16 + lr + r;
                 if (ci < p.Cin) out[((long)tap * p.Cin + ci) * p.N + n] = acc[i][j][r];
             }
         }
 }
+typedef void (*wgrad_kernel_t)(const WgradParams);
+struct WgradCfg {
+    int tc, tn;
+    wgrad_kernel_t fn;
+};
+#define WGCFG(WC, WN_, TI, TJ) {16 * TI * WC, 16 * TJ * WN_, wgrad_mfma_kernel<WC, WN_, TI, TJ>}
+static const WgradCfg kWgrad[] = {
+    WGCFG(2, 2, 2, 2),      // 64 x 64
+    WGCFG(1, 4, 1, 2),      // 16 x 128
+    WGCFG(1, 4, 2, 2),      // 32 x 128
+    WGCFG(1, 4, 1, 1),      // 16 x 64
+    WGCFG(2, 2, 1, 2),      // 32 x 64
+    WGCFG(4, 1, 2, 1),      // 128 x 16
+    WGCFG(4, 1, 2, 2),      // 128 x 32
+    WGCFG(2, 2, 2, 1),      // 64 x 32
+    WGCFG(4, 1, 1, 1),      // 64 x 16
+};
 
 // ------------------------------------------------------------------ depthwise 3x3 backward
 struct DwBwdParams {
@@ -869,8 +912,17 @@ static int wgrad(ssd_train_state& s, const Layer& l, int B, const float* x, cons
     p.kh = l.kh; p.kw = l.kw; p.stride = l.stride; p.dil = l.dil; p.pad_t = l.pt; p.pad_l = l.pl;
     p.N = N; p.ldg = ldg; p.K = l.kh * l.kw * l.Cin;
     p.M = (long)B * l.Ho * l.Wo;
-    p.ctiles = (l.Cin + 63) / 64;
-    p.ntiles = (N + 63) / 64;
+    // least padded area; ties go to the larger tile (fewer workgroups re-reading the rows)
+    const WgradCfg* cfg = &kWgrad[0];
+    {
+        long best = -1;
+        for (const auto& c : kWgrad) {
+            const long area = (long)((l.Cin + c.tc - 1) / c.tc) * c.tc * ((N + c.tn - 1) / c.tn) * c.tn;
+            if (best < 0 || area < best || (area == best && (long)c.tc * c.tn > (long)cfg->tc * cfg->tn)) { best = area; cfg = &c; }
+        }
+    }
+    p.ctiles = (l.Cin + cfg->tc - 1) / cfg->tc;
+    p.ntiles = (N + cfg->tn - 1) / cfg->tn;
     p.vec_x = (l.Cin % 4 == 0) && (((uintptr_t)x & 15) == 0);
     p.vec_g = (ldg % 4 == 0) && (((uintptr_t)g & 15) == 0);
     const long tiles = (long)l.kh * l.kw * p.ctiles * p.ntiles;
@@ -886,7 +938,7 @@ static int wgrad(ssd_train_state& s, const Layer& l, int B, const float* x, cons
     if (rc) return rc;
     p.rows_per_chunk = rpc;
     p.partial = s.partial;
-    hipLaunchKernelGGL(wgrad_mfma_kernel, dim3((unsigned)tiles, (unsigned)chunks), dim3(256), 0, st, p);
+    hipLaunchKernelGGL(cfg->fn, dim3((unsigned)tiles, (unsigned)chunks), dim3(256), 0, st, p);
     SSD_LAUNCH_CHECK();
     return chunk_sum(s.partial, chunks, (long)kn, dW, st);
 }
