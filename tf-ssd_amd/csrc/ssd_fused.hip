@@ -507,18 +507,24 @@ __global__ __launch_bounds__(256) void mbv2_stem_kernel(const StemParams p) {
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     // weights (BatchNorm scale folded in) are staged once per persistent workgroup
-    // Conv1: the 27 x 4 weights (x BN scale) of this thread's 4 output channels stay in registers
-    // for the whole persistent loop -- the phase was LDS-read bound with the weights in LDS (3
-    // LDS reads per 4 packed FMAs; 100 of the kernel's 176 us)
-    const int c1g = (tid & 7) * 4;
-    f32x4 w1r[27], h1r;
+    // Conv1 on the MFMA: K = 27 taps x channels padded to 32 = 2 k-blocks of 16; lane (ch = l15, g4) holds
+    // the A fragments W[ch][k = kb*16 + g4*4 + s] * BN scale of both 16-channel tiles for the whole
+    // persistent loop (16 VGPRs; the VALU form held 27 x 4 weights per thread and ran at 36 % of the
+    // packed-FMA rate: 63 of the kernel's 131 us), and the patch offsets of ITS four k per k-block
+    f32x4 w1a[2][2];
+    int koff[2][4];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const float sc = p.s1[c1g + j];
-        h1r[j] = p.h1[c1g + j];
+    for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-        for (int k = 0; k < 27; ++k) w1r[k][j] = p.w1[(long)(c1g + j) * p.kpad1 + k] * sc;
-    }
+        for (int s4 = 0; s4 < 4; ++s4) {
+            const int k = kb * 16 + (lane >> 4) * 4 + s4;
+            koff[kb][s4] = k < 27 ? (k / 9) * (kSPW * 3) + (k % 9) : 0;      // (ky, kx*3 + ci) inside the patch
+#pragma unroll
+            for (int ct = 0; ct < 2; ++ct) {
+                const int ch = ct * 16 + (lane & 15);
+                w1a[ct][kb][s4] = k < 27 ? p.w1[(long)ch * p.kpad1 + k] * p.s1[ch] : 0.f;
+            }
+        }
     for (int e = tid; e < 9 * 32; e += 256) Wd[e] = p.wd[e] * p.sd[e & 31];
     for (int e = tid; e < 16 * 32; e += 256) {
         const int n = e >> 5, k = e & 31;
@@ -560,23 +566,52 @@ __global__ __launch_bounds__(256) void mbv2_stem_kernel(const StemParams p) {
         }
         __syncthreads();
 
-        // ---- Conv1 on the halo: item = (halo pixel, 4-channel group); it & 7 == tid & 7
-        for (int it = tid; it < ((p.ablate & 1) ? 0 : kSIH * kSIW * 8); it += 256) {
-            const int hp = it >> 3;
-            const int r = hp / kSIW, c = hp - r * kSIW;
-            f32x4 a = h1r;
-            const float* pp = patch + ((2 * r) * kSPW + 2 * c) * 3;
+        // ---- Conv1 on the halo (MFMA): 12 pixel tiles of 16 halo pixels, 3 per wave; B fragment = the
+        //      lane's pixel x its 4 k of the k-block, gathered from the patch with 4 ds_read_b32
+        if (!(p.ablate & 1)) {
+            constexpr int NHP = kSIH * kSIW;                       // 180 halo pixels
+            int hp[3], rr[3], cc[3];
+            const float* pp[3];
+            f32x4 a0[3], a1[3];
 #pragma unroll
-            for (int ky = 0; ky < 3; ++ky)
+            for (int q = 0; q < 3; ++q) {
+                hp[q] = (wave * 3 + q) * 16 + (lane & 15);
+                const int hpc = hp[q] < NHP ? hp[q] : NHP - 1;      // the last tile's tail reads a valid pixel, never stored
+                rr[q] = hpc / kSIW;
+                cc[q] = hpc - rr[q] * kSIW;
+                pp[q] = patch + ((2 * rr[q]) * kSPW + 2 * cc[q]) * 3;
+                a0[q] = *reinterpret_cast<const f32x4*>(H1 + (lane >> 4) * 4);
+                a1[q] = *reinterpret_cast<const f32x4*>(H1 + 16 + (lane >> 4) * 4);
+            }
+            // six independent accumulator chains (3 pixel tiles x 2 channel tiles) keep the matrix pipe issuing
 #pragma unroll
-                for (int kk = 0; kk < 9; ++kk)                      // (kx, ci) are contiguous in the patch row
-                    a += pp[ky * kSPW * 3 + kk] * w1r[ky * 9 + kk];
-            // ReLU6 inside the feature map, 0 outside (the depthwise pads Conv1's OUTPUT)
-            const bool in = (unsigned)(cy0 + r) < (unsigned)p.H1 && (unsigned)(cx0 + c) < (unsigned)p.W1;
-            const float hi = in ? 6.0f : 0.0f;
+            for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) a[j] = __builtin_amdgcn_fmed3f(a[j], 0.0f, hi);
-            *reinterpret_cast<f32x4*>(C1 + hp * kSLD + c1g) = a;
+                for (int s4 = 0; s4 < 4; ++s4) {
+                    float bq[3];
+#pragma unroll
+                    for (int q = 0; q < 3; ++q) bq[q] = pp[q][koff[kb][s4]];
+#pragma unroll
+                    for (int q = 0; q < 3; ++q) {
+                        a0[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(w1a[0][kb][s4], bq[q], a0[q], 0, 0, 0);
+                        a1[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(w1a[1][kb][s4], bq[q], a1[q], 0, 0, 0);
+                    }
+                }
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+                // ReLU6 inside the feature map, 0 outside (the depthwise pads Conv1's OUTPUT)
+                const bool in = (unsigned)(cy0 + rr[q]) < (unsigned)p.H1 && (unsigned)(cx0 + cc[q]) < (unsigned)p.W1;
+                const float hi = in ? 6.0f : 0.0f;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    a0[q][j] = __builtin_amdgcn_fmed3f(a0[q][j], 0.0f, hi);
+                    a1[q][j] = __builtin_amdgcn_fmed3f(a1[q][j], 0.0f, hi);
+                }
+                if (hp[q] < NHP) {
+                    *reinterpret_cast<f32x4*>(C1 + hp[q] * kSLD + (lane >> 4) * 4) = a0[q];
+                    *reinterpret_cast<f32x4*>(C1 + hp[q] * kSLD + 16 + (lane >> 4) * 4) = a1[q];
+                }
+            }
         }
         __syncthreads();
 
