@@ -11,7 +11,8 @@ hp = dict(train_utils.get_hyper_params("mobilenet_v2")); hp["total_labels"] = 21
 m = get_model(hp, max_batch=B)
 data_utils.synthetic_weights(m)
 x = h.to_dev(data_utils.synthetic_images(B))
-for opts in ({"fuse_blocks": 0}, {"fuse_blocks": 1, "use_graph": 0, "overlap_heads": 0}, {"fuse_blocks": 1, "use_graph": 1, "overlap_heads": 1}):
+for opts in ({"fuse_blocks": 0}, {"fuse_blocks": 1, "use_graph": 0, "overlap_heads": 0}, {"fuse_blocks": 1, "use_graph": 1, "overlap_heads": 1},
+             {"fuse_image": 2, "image_ticket": 1, "use_graph": 1}, {"fuse_image": 2, "image_ticket": 0, "tail_on_side": 1}):
     for k, v in opts.items():
         m.set_option(k, v)
     d0, p0 = m(x)
