@@ -525,7 +525,8 @@ def test_image_block_kernel_vs_layer_kernels(B, ticket):
         x = np.concatenate([x] * ((B + 7) // 8))[:B] * np.linspace(0.5, 1.0, B, dtype=np.float32)[:, None, None, None]
     m = get_model(hp, max_batch=B)
     m.set_weights(w)
-    names = ["block_%d_out" % k for k in (7, 8, 9, 10, 11, 12, 14, 15, 16)]
+    # block 13 (depthwise stride 2) also writes its expanded map -- SSD feature map 1 -- from the same kernel
+    names = ["block_%d_out" % k for k in (7, 8, 9, 10, 11, 12, 13, 14, 15, 16)] + ["block_13_expand_relu"]
     m.set_option("fuse_image", 0)
     d0, p0 = m(x)
     ref = {n: m.fetch_activation(n).copy() for n in names}
@@ -534,6 +535,7 @@ def test_image_block_kernel_vs_layer_kernels(B, ticket):
     m.set_option("fuse_image", 2)       # 2: wherever the kernel applies (1 = where it won the finalize-time race)
     d1, p1 = m(x)
     assert any(l["name"] == "block_7_fused" and l["flops"] > 0 for l in m.layers(B))
+    assert any(l["name"] == "block_13_fused" and l["flops"] > 0 for l in m.layers(B))
     got = {n: m.fetch_activation(n).copy() for n in names}
     for n in names:
         scale = np.abs(ref[n]).max()

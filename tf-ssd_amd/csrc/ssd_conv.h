@@ -50,6 +50,7 @@ struct FusedBlockParams {
     int groups;                 // G >= 1 (filled by the caller from image_block_groups)
     float* slabs;               // [G][B][Ho*Wo][Cout] partial sums (G > 1)
     unsigned* tickets;          // [B] arrival counters, zero between launches
+    float* e_out;               // optional: the expanded map [B,H,W,Ce] is ALSO written to HBM (block 13: SSD feature map 1)
     long long* dbg;             // optional per-phase cycle counters [blocks][8] (profiling builds)
     int ablate;                 // diagnostics: 1 skip expand MFMAs, 2 skip depthwise math, 4 skip project MFMAs, 8 skip expand epilogue math
 };

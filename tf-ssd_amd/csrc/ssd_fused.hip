@@ -435,7 +435,7 @@ static const FusedCfg kFused[] = {
 };
 
 static const FusedCfg* pick_fused(const FusedBlockParams& p) {
-    if (p.Ce % kCK != 0 || p.Cin % 4 != 0 || p.Cout % 4 != 0) return nullptr;
+    if (p.Ce % kCK != 0 || p.Cin % 4 != 0 || p.Cout % 4 != 0 || p.e_out) return nullptr;   // (the tile kernel never writes E out)
     const int cinp = p.Cin <= 16 ? 16 : (p.Cin == 24 ? 24 : (p.Cin <= 32 ? 32 : 0));
     const int ntc = p.Cout <= 32 ? 2 : (p.Cout <= 64 ? 4 : 0);
     if (!cinp || !ntc) return nullptr;

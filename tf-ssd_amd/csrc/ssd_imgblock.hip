@@ -62,8 +62,13 @@ __device__ __forceinline__ void wait_prefetch(f32x4 (&r)[N]) {
     for (int i = 0; i < N; ++i) asm volatile("" : "+v"(r[i]));
 }
 
-template <int CIN, int NT, int T>
+// S = 2 (block 13): the depthwise / project side works on the Ho x Wo output map (its own pixel space
+// qo = ro * (Wo + 1) + co, TO tiles per wave), every lane reads its 9 taps at (2 ro - pad + dy,
+// 2 co - pad + dx) of the E chunk; p.e_out != nullptr additionally writes E (after BN + ReLU6) to HBM
+// once -- block_13_expand_relu is SSD feature map 1 -- instead of writing it and reading it back.
+template <int CIN, int NT, int T, int S = 1>
 __global__ __launch_bounds__(kIThreads) void mbv2_image_block_kernel(const FusedBlockParams p) {
+    constexpr int TO = S == 1 ? T : 1;            // output pixel tiles per wave
     constexpr int KC = CIN / 16;                  // 16-wide k blocks of the expand
     constexpr int LDW = CIN + 8;                  // We chunk row stride: 18 / 26 / 42 quads (2 mod 4)
     constexpr int NCH = T == 1 ? 2 : 1;           // independent expand accumulator chains per tile
@@ -162,6 +167,26 @@ __global__ __launch_bounds__(kIThreads) void mbv2_image_block_kernel(const Fused
         for (int kc = 0; kc < KC; ++kc)
             xb[t][kc] = real[t] ? *reinterpret_cast<const f32x4*>(xp + kc * 16) : f32x4{0.f, 0.f, 0.f, 0.f};
     }
+    // output side: the same tiles for stride 1; the Ho x Wo map's own tiles for stride 2
+    const int Ho = p.Ho, Wo = p.Wo;
+    int qo[TO], opo[TO];   // E index of the window centre (stride 1) / origin (stride 2); ro * Wo + co
+    bool realo[TO];
+#pragma unroll
+    for (int t = 0; t < TO; ++t) {
+        if (S == 1) {
+            qo[t] = qs[t];
+            opo[t] = opix[t];
+            realo[t] = real[t];
+        } else {
+            const int Po = Wo + 1, tile = wave * TO + t;
+            const int q = tile * 16 + l15;
+            const int ro = q / Po, co = q - ro * Po;
+            realo[t] = tile * 16 < Ho * Po && q < Ho * Po && co < Wo;
+            // centre of the 3x3 window in E coordinates (TF SAME pads: pad_t / pad_l before)
+            qo[t] = (tile * 16 < Ho * Po && q < Ho * Po) ? (2 * ro - p.pad_t + 1) * P + (2 * co - p.pad_l + 1) : 0;
+            opo[t] = realo[t] ? ro * Wo + co : 0;
+        }
+    }
     for (int u = tid; u < 11 * (CeG / 4); u += kIThreads) {
         const int row = u / (CeG / 4), c4 = (u - row * (CeG / 4)) * 4;
         const float* src = row == 0 ? p.eh : row == 10 ? p.dh : p.wd + (long)(row - 1) * p.Ce;
@@ -202,12 +227,14 @@ __global__ __launch_bounds__(kIThreads) void mbv2_image_block_kernel(const Fused
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] = __builtin_amdgcn_fmed3f(v[e], 0.0f, hi);
             if (tvalid[t]) *reinterpret_cast<f32x4*>(es + qs[t] * kILD) = v;
+            if (p.e_out && real[t])
+                *reinterpret_cast<f32x4*>(p.e_out + ((long)img * H * W + opix[t]) * p.Ce + cbeg + j * kIC + g4 * 4) = v;
         }
     };
 
-    f32x4 acc[T][NT];
+    f32x4 acc[TO][NT];
 #pragma unroll
-    for (int t = 0; t < T; ++t)
+    for (int t = 0; t < TO; ++t)
 #pragma unroll
         for (int ni = 0; ni < NT; ++ni) acc[t][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
 
@@ -233,14 +260,14 @@ __global__ __launch_bounds__(kIThreads) void mbv2_image_block_kernel(const Fused
         }
         ITICK(4);
         // ---- depthwise in MFMA-fragment layout
-        f32x4 a[T];
+        f32x4 a[TO];
         if (p.ablate & 2) {
 #pragma unroll
-            for (int t = 0; t < T; ++t) a[t] = f32x4{1.f, 1.f, 1.f, 1.f};
+            for (int t = 0; t < TO; ++t) a[t] = f32x4{1.f, 1.f, 1.f, 1.f};
         } else {
             const f32x4 dh = *reinterpret_cast<const f32x4*>(Ps + 10 * CeG + i * kIC + g4 * 4);
 #pragma unroll
-            for (int t = 0; t < T; ++t) a[t] = dh;
+            for (int t = 0; t < TO; ++t) a[t] = dh;
             const float* es = Es + ((i & 1) * NE + P + 1) * kILD + g4 * 4;
 #pragma unroll
             for (int dy = -1; dy <= 1; ++dy)
@@ -248,13 +275,13 @@ __global__ __launch_bounds__(kIThreads) void mbv2_image_block_kernel(const Fused
                 for (int dx = -1; dx <= 1; ++dx) {
                     const f32x4 w = *reinterpret_cast<const f32x4*>(Ps + (1 + (dy + 1) * 3 + dx + 1) * CeG + i * kIC + g4 * 4);
 #pragma unroll
-                    for (int t = 0; t < T; ++t) {
-                        const f32x4 e = *reinterpret_cast<const f32x4*>(es + (qs[t] + dy * P + dx) * kILD);
+                    for (int t = 0; t < TO; ++t) {
+                        const f32x4 e = *reinterpret_cast<const f32x4*>(es + (qo[t] + dy * P + dx) * kILD);
                         a[t] += e * w;
                     }
                 }
 #pragma unroll
-            for (int t = 0; t < T; ++t)
+            for (int t = 0; t < TO; ++t)
 #pragma unroll
                 for (int e = 0; e < 4; ++e) a[t][e] = __builtin_amdgcn_fmed3f(a[t][e], 0.0f, 6.0f);
         }
@@ -269,7 +296,7 @@ __global__ __launch_bounds__(kIThreads) void mbv2_image_block_kernel(const Fused
 #pragma unroll
                 for (int s = 0; s < 4; ++s)
 #pragma unroll
-                    for (int t = 0; t < T; ++t)
+                    for (int t = 0; t < TO; ++t)
                         acc[t][ni] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[s], a[t][s], acc[t][ni], 0, 0, 0);
             }
         }
@@ -280,17 +307,17 @@ __global__ __launch_bounds__(kIThreads) void mbv2_image_block_kernel(const Fused
     }
 
     // ---- epilogue
-    const long img_off = (long)img * H * W * p.Cout;
+    const long img_off = (long)img * Ho * Wo * p.Cout;
     if (G == 1) {
 #pragma unroll
-        for (int t = 0; t < T; ++t) {
-            if (!real[t]) continue;
-            float* yp = p.y + img_off + (long)opix[t] * p.Cout + g4 * 4;
+        for (int t = 0; t < TO; ++t) {
+            if (!realo[t]) continue;
+            float* yp = p.y + img_off + (long)opo[t] * p.Cout + g4 * 4;
 #pragma unroll
             for (int ni = 0; ni < NT; ++ni) {
                 f32x4 v = acc[t][ni] + *reinterpret_cast<const f32x4*>(p.ph + ni * 16 + g4 * 4);
                 if (p.residual)                                     // Cin == Cout: same layout as y
-                    v = v + *reinterpret_cast<const f32x4*>(p.x + img_off + (long)opix[t] * p.Cout + ni * 16 + g4 * 4);
+                    v = v + *reinterpret_cast<const f32x4*>(p.x + img_off + (long)opo[t] * p.Cout + ni * 16 + g4 * 4);
                 *reinterpret_cast<f32x4*>(yp + ni * 16) = v;
             }
         }
@@ -299,16 +326,16 @@ __global__ __launch_bounds__(kIThreads) void mbv2_image_block_kernel(const Fused
         return;
     }
     if (p.ablate & 16) return;
-    const long slab_stride = (long)B * H * W * p.Cout;              // between groups
+    const long slab_stride = (long)B * Ho * Wo * p.Cout;              // between groups
     {
         float* sp = p.slabs + (long)grp * slab_stride + img_off + g4 * 4;
 #pragma unroll
-        for (int t = 0; t < T; ++t) {
-            if (!real[t]) continue;
+        for (int t = 0; t < TO; ++t) {
+            if (!realo[t]) continue;
 #pragma unroll
             for (int ni = 0; ni < NT; ++ni)
-                if (p.tickets) gstore16_sc1(sp + (long)opix[t] * p.Cout + ni * 16, acc[t][ni]);
-                else *reinterpret_cast<f32x4*>(sp + (long)opix[t] * p.Cout + ni * 16) = acc[t][ni];
+                if (p.tickets) gstore16_sc1(sp + (long)opo[t] * p.Cout + ni * 16, acc[t][ni]);
+                else *reinterpret_cast<f32x4*>(sp + (long)opo[t] * p.Cout + ni * 16) = acc[t][ni];
         }
     }
     if (!p.tickets) {        // combine by the follow-up kernel (image_combine_kernel): the launch boundary publishes the slabs
@@ -341,7 +368,7 @@ __global__ __launch_bounds__(kIThreads) void mbv2_image_block_kernel(const Fused
     // groups per round trip, changed nothing.)
     {
         const int c4n = p.Cout / 4;
-        const int nvec = H * W * c4n;
+        const int nvec = Ho * Wo * c4n;
         const float* s0 = p.slabs + img_off;
         const float* xr = p.x + img_off;                             // residual: Cin == Cout, same layout
         float* yo = p.y + img_off;
@@ -390,16 +417,18 @@ __global__ __launch_bounds__(256) void image_combine_kernel(const float* __restr
 
 typedef void (*image_kernel_t)(const FusedBlockParams);
 struct ImageCfg {
-    int cin, nt, t;
+    int cin, nt, t, stride;
     image_kernel_t fn;
 };
-#define ICFG(CIN, NT, T) {CIN, NT, T, mbv2_image_block_kernel<CIN, NT, T>}
+#define ICFG(CIN, NT, T) {CIN, NT, T, 1, mbv2_image_block_kernel<CIN, NT, T, 1>}
+#define ICFG2(CIN, NT, T) {CIN, NT, T, 2, mbv2_image_block_kernel<CIN, NT, T, 2>}
 const ImageCfg kImage[] = {
     ICFG(64, 4, 3),     // blocks 7-9:   64 -> 384 -> 64 at 19x19
     ICFG(64, 6, 3),     // block 10:     64 -> 384 -> 96
     ICFG(96, 6, 3),     // blocks 11-12: 96 -> 576 -> 96
     ICFG(160, 10, 1),   // blocks 14-15: 160 -> 960 -> 160 at 10x10
     ICFG(160, 20, 1),   // block 16:     160 -> 960 -> 320
+    ICFG2(96, 10, 3),   // block 13:     96 -> 576 -> 160, depthwise stride 2 (19x19 -> 10x10), E written out
 };
 
 size_t image_lds_bytes(const ImageCfg& c, const FusedBlockParams& p, int G) {
@@ -410,13 +439,17 @@ size_t image_lds_bytes(const ImageCfg& c, const FusedBlockParams& p, int G) {
 }
 
 const ImageCfg* pick_image(const FusedBlockParams& p) {
-    if (p.stride != 1 || p.H != p.Ho || p.W != p.Wo || p.Ce % kIC != 0 || p.Cout % 16 != 0) return nullptr;
-    if (p.kpad_e % 4 != 0 || p.kpad_p % 4 != 0) return nullptr;
+    if (p.Ce % kIC != 0 || p.Cout % 16 != 0 || p.kpad_e % 4 != 0 || p.kpad_p % 4 != 0) return nullptr;
+    if (p.stride == 1 && (p.H != p.Ho || p.W != p.Wo)) return nullptr;
+    if (p.stride == 2 && (p.residual || p.Ho != (p.H + 1) / 2 || p.Wo != (p.W + 1) / 2 || p.pad_t > 1 || p.pad_l > 1 ||
+                          (p.Ho * (p.Wo + 1) + 15) / 16 > 8))
+        return nullptr;
+    if (p.stride != 1 && p.stride != 2) return nullptr;
     if (p.residual && p.Cin != p.Cout) return nullptr;
     const int npt = (p.H * (p.W + 1) + 15) / 16;
     for (const auto& c : kImage)
-        if (c.cin == p.Cin && c.nt * 16 == p.Cout && npt <= 8 * c.t && npt > 8 * (c.t == 3 ? 1 : 0) &&
-            image_lds_bytes(c, p, 1) + 11 * p.Ce * 0 <= 160 * 1024)
+        if (c.cin == p.Cin && c.nt * 16 == p.Cout && c.stride == p.stride && npt <= 8 * c.t && npt > 8 * (c.t == 3 ? 1 : 0) &&
+            image_lds_bytes(c, p, 1) <= 160 * 1024)
             return &c;
     return nullptr;
 }
@@ -447,7 +480,7 @@ int image_block_groups(const FusedBlockParams& p, int B) {
 
 size_t image_block_slab_floats(const FusedBlockParams& p, int B) {
     const int G = image_block_groups(p, B);
-    return G > 1 ? (size_t)G * B * p.H * p.W * p.Cout : 0;
+    return G > 1 ? (size_t)G * B * p.Ho * p.Wo * p.Cout : 0;
 }
 
 int launch_image_block(FusedBlockParams p, hipStream_t st) {
@@ -472,7 +505,7 @@ int launch_image_block(FusedBlockParams p, hipStream_t st) {
     hipLaunchKernelGGL(c->fn, dim3((unsigned)((long)p.B * p.groups)), dim3(kIThreads), lds, st, p);
     SSD_LAUNCH_CHECK();
     if (p.groups > 1 && !p.tickets && !(p.ablate & 24)) {
-        const long nvec = (long)p.B * p.H * p.W * p.Cout / 4;
+        const long nvec = (long)p.B * p.Ho * p.Wo * p.Cout / 4;
         const int blocks = (int)((nvec + 255) / 256 < 4096 ? (nvec + 255) / 256 : 4096);
         hipLaunchKernelGGL(image_combine_kernel, dim3(blocks), dim3(256), 0, st, p.slabs, p.ph, p.residual ? p.x : nullptr, p.y,
                            nvec, nvec, p.groups, p.Cout / 4);

@@ -58,6 +58,7 @@ struct Layer {
     int f_type = 0;                 // 0: inverted-residual block, 1: stem (Conv1 -> dw -> project),
                                     // 2: depthwise + project (the expand conv stays a GEMM of its own)
     int fused_by = -1;
+ int e_out = -1;                 // whole-block LK_FUSED layer that must ALSO materialise its expanded map: that tensor
     int img_choice = -1;            // whole-block LK_FUSED layers the image kernel can run: 1 = it won the finalize-time race against the layer kernels, 0 = it lost, -1 = not timed
     int fused_by2 = -1;             // depthwise / project members: their type-2 LK_FUSED layer
     float* splitk_part = nullptr;   // this layer's own split-K slab (layers may run concurrently)

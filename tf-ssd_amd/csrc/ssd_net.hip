@@ -207,11 +207,14 @@ static void build_mobilenet_v2(ssd_net& net) {
         x = b.conv(p + "project", p + "out", x, cout, 1, 1, 1, 1, p + "project_BN", false, SSD_ACT_NONE,
                    res ? inp : -1);
         int ie = (int)net.layers.size() - 3;      // expand, depthwise = ie + 1, project = ie + 2
-        if (k != 13) {      // block 13's expanded map is SSD feature map #1: it must reach HBM
+        {
             Layer f;
             f.name = p + "fused";
             f.kind = LK_FUSED;
             f.in = inp; f.out = x;
+            // block 13's expanded map is SSD feature map #1: it must reach HBM -- only the whole-image
+            // kernel takes that block (it writes E out once), the tile kernel never does (Cin = 96)
+            if (k == 13) f.e_out = tap1;
             const Layer& le = net.layers[ie];
             const Layer& ld = net.layers[ie + 1];
             f.H = le.H; f.W = le.W; f.Cin = le.Cin; f.Ho = ld.Ho; f.Wo = ld.Wo; f.Cout = cout;
@@ -350,6 +353,7 @@ static FusedBlockParams fused_params(const ssd_net& net, const Layer& f, int B) 
     p.kpad_e = conv_kpad(le.Cin);
     p.kpad_p = conv_kpad(lp.Cin);
     p.npad_p = conv_npad(lp.Cout);
+    p.e_out = f.e_out >= 0 ? net.tensors[f.e_out].dev : nullptr;
     if (!fused_block_supported(p) && image_block_supported(p)) {
         p.groups = net.img_slabs ? image_block_groups(p, B) : 1;
         p.slabs = net.img_slabs;
@@ -1026,7 +1030,7 @@ static int forward_impl(ssd_net* net, const float* image_dev, int B, float* delt
             const Layer& h = net->layers[j];
             if (h.side != 2 || !layer_runs(*net, h)) continue;
             for (int q = j - 1; q >= 0; --q)
-                if (net->layers[q].out == h.in && layer_runs(*net, net->layers[q])) { split = q; break; }
+                if ((net->layers[q].out == h.in || net->layers[q].e_out == h.in) && layer_runs(*net, net->layers[q])) { split = q; break; }
         }
         std::vector<char> placed(nl, 0);
         auto place_small_heads = [&](int out_tensor) {
@@ -1048,7 +1052,7 @@ static int forward_impl(ssd_net* net, const float* image_dev, int B, float* delt
             if (net->layers[i].side != 1) continue;
             // (VGG16: the L2 normalisation feeding head 1 sits behind the extras in the layer list)
             for (int j = i - 1; j >= 0; --j)
-                if (net->layers[j].out == net->layers[i].in && layer_runs(*net, net->layers[j])) {
+                if ((net->layers[j].out == net->layers[i].in || net->layers[j].e_out == net->layers[i].in) && layer_runs(*net, net->layers[j])) {
                     if (!placed[j]) { order.push_back(j); placed[j] = 1; }
                     break;
                 }
@@ -1075,7 +1079,7 @@ static int forward_impl(ssd_net* net, const float* image_dev, int B, float* delt
     auto stream_of = [&](int i) { return sid[i] < 0 ? st : net->side[sid[i]]; };
     auto producer_of = [&](int i, int tensor) {
         for (int j = i - 1; j >= 0; --j)
-            if (net->layers[j].out == tensor && layer_runs(*net, net->layers[j])) return j;
+            if ((net->layers[j].out == tensor || net->layers[j].e_out == tensor) && layer_runs(*net, net->layers[j])) return j;      // (e_out: block 13's whole-image kernel also produces its expanded map)
         return -1;
     };
     // a layer publishes its completion (ev_ready on ITS stream) when a consumer runs on another stream
