@@ -488,7 +488,11 @@ static int tune_image_blocks(ssd_net& net, int B, hipStream_t st) {
     ScopedEvent se0, se1;
     SSD_HIP(hipEventCreate(&se0.e));
     SSD_HIP(hipEventCreate(&se1.e));
-    const int mode = net.fuse_image;
+    struct ModeGuard {          // the race runs in "tuned choice" mode; early error returns restore the caller's mode too
+        ssd_net& n;
+        int mode;
+        ~ModeGuard() { n.fuse_image = mode; }
+    } guard{net, net.fuse_image};
     net.fuse_image = 1;
     int rc = SSD_OK;
     for (size_t fi = 0; fi < net.layers.size() && !rc; ++fi) {
@@ -514,7 +518,6 @@ static int tune_image_blocks(ssd_net& net, int B, hipStream_t st) {
         }
         f.img_choice = ms[1] < ms[0] ? 1 : 0;
     }
-    net.fuse_image = mode;
     return rc;
 }
 
