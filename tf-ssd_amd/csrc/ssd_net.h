@@ -106,6 +106,7 @@ struct ssd_net {
     std::map<std::string, std::pair<std::string, int>> preset;   // layer -> (config name, split_k)
     // hipGraph replay of a whole forward/predict step, keyed by every pointer baked into it
     bool use_graph = true;
+    bool use_graph_auto = true;     // finalize races graph replay against direct launches (until "use_graph" is set explicitly)
     struct GraphEntry {
         std::vector<const void*> key;
         hipGraphExec_t exec = nullptr;

@@ -727,6 +727,44 @@ int ssd_net_get_param(const ssd_net* net, const char* name, float* host_out, siz
     return SSD_OK;
 }
 
+// hipGraph replay vs direct launches of the whole forward, raced on the device at max_batch on a zero
+// image (measured at B=64: direct launches 1.950 ms, replay 1.972 ms per step on a non-default stream;
+// replay is immune to a slow host, so it wins ties).  Skipped once "use_graph" was set explicitly.
+static int tune_launch_mode(ssd_net* net, int B) {
+    if (!net->use_graph_auto || net->timing) return SSD_OK;
+    const size_t n_img = (size_t)B * net->img_size * net->img_size * 3;
+    ScopedDev img, del, prb;
+    SSD_HIP(hipMalloc((void**)&img.p, n_img * sizeof(float)));
+    SSD_HIP(hipMalloc((void**)&del.p, (size_t)B * net->num_priors * 4 * sizeof(float)));
+    SSD_HIP(hipMalloc((void**)&prb.p, (size_t)B * net->num_priors * net->L * sizeof(float)));
+    SSD_HIP(hipMemset(img.p, 0, n_img * sizeof(float)));
+    hipStream_t st = nullptr;
+    SSD_HIP(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+    ScopedEvent e0, e1;
+    int rc = SSD_OK;
+    float ms[2] = {1e30f, 1e30f};
+    if (hipEventCreate(&e0.e) != hipSuccess || hipEventCreate(&e1.e) != hipSuccess) rc = SSD_E_HIP;
+    for (int mode = 0; mode < 2 && !rc; ++mode) {
+        net->use_graph = mode != 0;
+        for (int w = 0; w < 3 && !rc; ++w) rc = ssd_net_forward(net, img.p, B, del.p, prb.p, st);     // eager, capture, replay
+        for (int trial = 0; trial < 2 && !rc; ++trial) {
+            (void)hipEventRecord(e0.e, st);
+            for (int r = 0; r < 6 && !rc; ++r) rc = ssd_net_forward(net, img.p, B, del.p, prb.p, st);
+            (void)hipEventRecord(e1.e, st);
+            if (rc || hipEventSynchronize(e1.e) != hipSuccess) { rc = rc ? rc : SSD_E_HIP; break; }
+            float t = 0.f;
+            (void)hipEventElapsedTime(&t, e0.e, e1.e);
+            if (t < ms[mode]) ms[mode] = t;
+        }
+    }
+    (void)hipStreamSynchronize(st);
+    net->drop_graphs();
+    (void)hipStreamDestroy(st);
+    net->tensors[0].dev = nullptr;
+    net->use_graph = rc ? true : ms[1] <= ms[0] * 1.005f;
+    return rc;
+}
+
 int ssd_net_finalize(ssd_net* net, int max_batch) {
     SSD_CHECK_ARG(net && max_batch >= 1, "ssd_net_finalize: bad arguments");
     for (const auto& p : net->params)
@@ -941,7 +979,7 @@ int ssd_net_finalize(ssd_net* net, int max_batch) {
     SSD_HIP(hipDeviceSynchronize());
     net->drop_graphs();
     net->finalized = true;
-    return SSD_OK;
+    return tune_launch_mode(net, max_batch);
 }
 
 // Tuning table as text, one "layer config split_k" line per conv layer.
@@ -1306,6 +1344,7 @@ int ssd_net_set_option(ssd_net* net, const char* name, int value) {
     }
     if (std::string(name) == "use_graph") {
         net->use_graph = value != 0;
+        net->use_graph_auto = false;
         net->drop_graphs();
         return SSD_OK;
     }
