@@ -269,8 +269,8 @@ double ssd_net_layer_bytes(const ssd_net* net, int i, int B); /* in + out + weig
 double ssd_net_layer_executed_flops(const ssd_net* net, int i, int B);
 /* Options: "use_graph" replays each forward/predict step as one captured hipGraph (keyed by the
  * pointers/sizes of the call; the NULL stream is served through an internal stream) -- by default
- * ssd_net_finalize races replay against direct launches on the device and keeps the faster (replay on
- * ties); setting the option pins the mode;
+ * ssd_net_finalize races replay against direct launches on the device at max_batch and uses replay only
+ * where it is more than 1 % ahead; setting the option pins the mode;
  * "fuse_blocks" (default 1) runs eligible MobileNetV2 inverted-residual blocks
  * (expand -> depthwise -> project) as one fused kernel; 0 runs them as three layers (then
  * every intermediate activation is inspectable); "fuse_dwproj" (default 1, needs fuse_blocks)
