@@ -683,6 +683,10 @@ ssd_net* ssd_net_create(int backbone, int img_size, int levels, const int* n_ars
         }
     if (backbone == SSD_MOBILENET_V2) build_mobilenet_v2(*net);
     else build_vgg16(*net);
+    if (const char* g = getenv("SSD_HIP_USE_GRAPH")) {      // diagnostics: pin the launch mode (0 direct, 1 graph replay)
+        net->use_graph = atoi(g) != 0;
+        net->use_graph_auto = false;
+    }
     return net.release();
 }
 
