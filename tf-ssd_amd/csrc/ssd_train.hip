@@ -536,6 +536,9 @@ static const WgradCfg kWgrad[] = {
     WGCFG(4, 1, 2, 2),      // 128 x 32
     WGCFG(2, 2, 2, 1),      // 64 x 32
     WGCFG(4, 1, 1, 1),      // 64 x 16
+    WGCFG(2, 2, 4, 4),      // 128 x 128
+    WGCFG(2, 2, 4, 2),      // 128 x 64
+    WGCFG(2, 2, 2, 4),      // 64 x 128
 };
 
 // ------------------------------------------------------------------ depthwise 3x3 backward
@@ -912,13 +915,19 @@ static int wgrad(ssd_train_state& s, const Layer& l, int B, const float* x, cons
     p.kh = l.kh; p.kw = l.kw; p.stride = l.stride; p.dil = l.dil; p.pad_t = l.pt; p.pad_l = l.pl;
     p.N = N; p.ldg = ldg; p.K = l.kh * l.kw * l.Cin;
     p.M = (long)B * l.Ho * l.Wo;
-    // least padded area; ties go to the larger tile (fewer workgroups re-reading the rows)
+    // Least padded tile area first (MFMA work); among equals the shape that stages the fewest floats per M
+    // row (every tile re-reads its 32-row slabs of X and G: ctiles * ntiles * (tc + tn)).  Measured: by
+    // staged floats alone 128 x 128 wins everywhere, +4 % on VGG16 (512-channel layers, no padding) but
+    // -3 % on MobileNetV2 (96 -> 576 expands padded to 128 x 640); the lexicographic rule keeps both.
     const WgradCfg* cfg = &kWgrad[0];
     {
-        long best = -1;
+        long best_area = -1, best_staged = -1;
         for (const auto& c : kWgrad) {
-            const long area = (long)((l.Cin + c.tc - 1) / c.tc) * c.tc * ((N + c.tn - 1) / c.tn) * c.tn;
-            if (best < 0 || area < best || (area == best && (long)c.tc * c.tn > (long)cfg->tc * cfg->tn)) { best = area; cfg = &c; }
+            const long ct = (l.Cin + c.tc - 1) / c.tc, nt = (N + c.tn - 1) / c.tn;
+            const long area = ct * c.tc * nt * c.tn, staged = ct * nt * (c.tc + c.tn);
+            if (best_area < 0 || area < best_area || (area == best_area && staged < best_staged)) {
+                best_area = area; best_staged = staged; cfg = &c;
+            }
         }
     }
     p.ctiles = (l.Cin + cfg->tc - 1) / cfg->tc;
