@@ -563,22 +563,45 @@ __global__ __launch_bounds__(256) void dw_wgrad_kernel(const DwBwdParams p) {
 #pragma unroll
     for (int t = 0; t < 9; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
     if (c < p.C) {
-        for (long m = r0 + rl; m < r1; m += 16) {
+        // row lane rl walks a CONTIGUOUS run of output pixels with a sliding 3x3 window of x in registers:
+        // along a row each step loads one new column (stride 1) or two (stride 2) instead of nine taps
+        const long seg = (r1 - r0 + 15) / 16;
+        const long mb = r0 + rl * seg, me = mb + seg < r1 ? mb + seg : r1;
+        f32x4 xw[3][3];
+        int pox = -2, poy = -1, pb = -1;
+        const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+        for (long m = mb; m < me; ++m) {
             const int ox = (int)(m % p.Wo);
             const long r = m / p.Wo;
             const int oy = (int)(r % p.Ho), b = (int)(r / p.Ho);
             const f32x4 g = *reinterpret_cast<const f32x4*>(p.g + m * p.C + c);
+            const bool slide = ox == pox + 1 && oy == poy && b == pb;
+            const int first = slide ? 3 - p.stride : 0;            // first window column to (re)load
+            if (slide) {
+#pragma unroll
+                for (int ky = 0; ky < 3; ++ky) {
+                    if (p.stride == 1) { xw[ky][0] = xw[ky][1]; xw[ky][1] = xw[ky][2]; }
+                    else xw[ky][0] = xw[ky][2];
+                }
+            }
 #pragma unroll
             for (int ky = 0; ky < 3; ++ky) {
                 const int iy = oy * p.stride - p.pad_t + ky;
-                if ((unsigned)iy >= (unsigned)p.H) continue;
+                const bool rowok = (unsigned)iy < (unsigned)p.H;
 #pragma unroll
                 for (int kx = 0; kx < 3; ++kx) {
+                    if (kx < first) continue;
                     const int ix = ox * p.stride - p.pad_l + kx;
-                    if ((unsigned)ix >= (unsigned)p.W) continue;
-                    acc[ky * 3 + kx] += *reinterpret_cast<const f32x4*>(p.x + (((long)b * p.H + iy) * p.W + ix) * p.C + c) * g;
+                    xw[ky][kx] = (rowok && (unsigned)ix < (unsigned)p.W)
+                                     ? *reinterpret_cast<const f32x4*>(p.x + (((long)b * p.H + iy) * p.W + ix) * p.C + c)
+                                     : zero;
                 }
             }
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx) acc[ky * 3 + kx] += xw[ky][kx] * g;
+            pox = ox; poy = oy; pb = b;
         }
     }
     float* out = p.partial + (long)blockIdx.y * 9 * p.C;
@@ -625,6 +648,47 @@ __global__ __launch_bounds__(256) void dw_dgrad_kernel(const DwBwdParams p) {
         }
         f32x4* d = reinterpret_cast<f32x4*>(p.dx + (((long)b * p.H + iy) * p.W + ix) * p.C + c);
         *d = p.accumulate ? *d + acc : acc;
+    }
+}
+
+// stride-1 form (13 of the 17 depthwise layers): thread = 4 consecutive ix x 4 channels; the 3 x 6 window
+// of dY serves all four outputs (4.5 loads per output instead of 9)
+__global__ __launch_bounds__(256) void dw_dgrad4_kernel(const DwBwdParams p) {
+    const int C4 = p.C >> 2, W4 = (p.W + 3) >> 2;
+    const long total = (long)p.B * p.H * W4 * C4;
+    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+        const int c = (int)(e % C4) * 4;
+        long r = e / C4;
+        const int ix0 = (int)(r % W4) * 4;
+        r /= W4;
+        const int iy = (int)(r % p.H), b = (int)(r / p.H);
+        f32x4 acc[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) {
+            const int oy = iy + p.pad_t - ky;
+            if ((unsigned)oy >= (unsigned)p.Ho) continue;
+            f32x4 g[6];
+#pragma unroll
+            for (int q = 0; q < 6; ++q) {
+                const int ox = ix0 + p.pad_l - 2 + q;            // = (ix0 + j) + pad_l - kx  for  q = j + 2 - kx
+                g[q] = (unsigned)ox < (unsigned)p.Wo ? *reinterpret_cast<const f32x4*>(p.g + (((long)b * p.Ho + oy) * p.Wo + ox) * p.C + c)
+                                                     : f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+                const f32x4 w = *reinterpret_cast<const f32x4*>(p.w + (ky * 3 + kx) * p.C + c);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[j] += g[j + 2 - kx] * w;
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if (ix0 + j >= p.W) break;
+            f32x4* d = reinterpret_cast<f32x4*>(p.dx + (((long)b * p.H + iy) * p.W + ix0 + j) * p.C + c);
+            *d = p.accumulate ? *d + acc[j] : acc[j];
+        }
     }
 }
 
@@ -1357,7 +1421,10 @@ int ssd_net_train_forward_backward(ssd_net* net, const float* image_dev, int B, 
             hipLaunchKernelGGL(dw_wgrad_kernel, dim3(ctiles, (unsigned)chunks), dim3(256), 0, st, dp);
             rc = chunk_sum(s.partial, chunks, 9L * l.Cin, grads_flat_dev + t.g_kernel, st);
             if (rc) return rc;
-            hipLaunchKernelGGL(dw_dgrad_kernel, dim3(grid_for((long)B * l.H * l.W * (l.Cin / 4))), dim3(256), 0, st, dp);
+            if (l.stride == 1)
+                hipLaunchKernelGGL(dw_dgrad4_kernel, dim3(grid_for((long)B * l.H * ((l.W + 3) / 4) * (l.Cin / 4))), dim3(256), 0, st, dp);
+            else
+                hipLaunchKernelGGL(dw_dgrad_kernel, dim3(grid_for((long)B * l.H * l.W * (l.Cin / 4))), dim3(256), 0, st, dp);
             SSD_LAUNCH_CHECK();
             s.gwritten[l.in] = 1;
             continue;
