@@ -415,6 +415,7 @@ struct WgradParams {
     long M, rows_per_chunk;
     int ctiles, ntiles;   // channel tiles per tap, n tiles
     int vec_x, vec_g;
+    int im2col;           // 1 (Cin % 4 != 0: the RGB stems): a tile's rows are k = (tap, ci) jointly, one "tap"
 };
 // Tile shape = (WC x WN wave grid) x (TI x TJ 16x16 MFMA tiles per wave): TC = 16*TI*WC input channels by
 // TN = 16*TJ*WN output channels.  MobileNetV2 has many 16-32 channel sides (a 16 -> 96 expand fills 19 %
@@ -433,9 +434,10 @@ __global__ __launch_bounds__(256) void wgrad_mfma_kernel(const WgradParams p) {
     int t = blockIdx.x;
     const int nt = t % p.ntiles;
     t /= p.ntiles;
-    const int ct = t % p.ctiles, tap = t / p.ctiles;
+    const int ct = t % p.ctiles, tap = t / p.ctiles;           // im2col: tap == 0
     const int ky = tap / p.kw, kx = tap % p.kw;
     const int c0 = ct * TC, n0 = nt * TN;
+    const int climit = p.im2col ? p.K : p.Cin;                  // valid rows of the tile
     const long mBeg = (long)blockIdx.y * p.rows_per_chunk;
     const long mEnd = mBeg + p.rows_per_chunk < p.M ? mBeg + p.rows_per_chunk : p.M;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -454,7 +456,21 @@ __global__ __launch_bounds__(256) void wgrad_mfma_kernel(const WgradParams p) {
             const int row = u / XQ, q = (u - row * XQ) * 4;
             const long m = m0 + row;
             f32x4 xv = {0.f, 0.f, 0.f, 0.f};
-            if (m < mEnd) {
+            if (m < mEnd && p.im2col) {
+                // K = kh*kw*Cin is small (27 for the RGB stems): the tile row index IS k = tap * Cin + ci
+                const int ox = (int)(m % p.Wo);
+                const long r = m / p.Wo;
+                const int oy = (int)(r % p.Ho), b = (int)(r / p.Ho);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int k = c0 + q + j;
+                    if (k >= p.K) continue;
+                    const int tp = k / p.Cin, ci = k - tp * p.Cin;
+                    const int iy = oy * p.stride - p.pad_t + (tp / p.kw) * p.dil, ix = ox * p.stride - p.pad_l + (tp % p.kw) * p.dil;
+                    if ((unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W)
+                        xv[j] = p.x[(((long)b * p.H + iy) * p.W + ix) * p.Cin + ci];
+                }
+            } else if (m < mEnd) {
                 const int ox = (int)(m % p.Wo);
                 const long r = m / p.Wo;
                 const int oy = (int)(r % p.Ho), b = (int)(r / p.Ho);
@@ -516,7 +532,7 @@ __global__ __launch_bounds__(256) void wgrad_mfma_kernel(const WgradParams p) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int ci = c0 + (wk * TI + i) * 16 + lr + r;
-                if (ci < p.Cin) out[((long)tap * p.Cin + ci) * p.N + n] = acc[i][j][r];
+                if (ci < climit) out[((long)tap * p.Cin + ci) * p.N + n] = acc[i][j][r];
             }
         }
 }
@@ -983,22 +999,24 @@ static int wgrad(ssd_train_state& s, const Layer& l, int B, const float* x, cons
     // row (every tile re-reads its 32-row slabs of X and G: ctiles * ntiles * (tc + tn)).  Measured: by
     // staged floats alone 128 x 128 wins everywhere, +4 % on VGG16 (512-channel layers, no padding) but
     // -3 % on MobileNetV2 (96 -> 576 expands padded to 128 x 640); the lexicographic rule keeps both.
+    p.im2col = l.Cin % 4 != 0;            // RGB stems (Cin = 3): one tile spans all K = 27 rows instead of 3 of 16 per tap
+    const int rows = p.im2col ? p.K : l.Cin;
     const WgradCfg* cfg = &kWgrad[0];
     {
         long best_area = -1, best_staged = -1;
         for (const auto& c : kWgrad) {
-            const long ct = (l.Cin + c.tc - 1) / c.tc, nt = (N + c.tn - 1) / c.tn;
+            const long ct = (rows + c.tc - 1) / c.tc, nt = (N + c.tn - 1) / c.tn;
             const long area = ct * c.tc * nt * c.tn, staged = ct * nt * (c.tc + c.tn);
             if (best_area < 0 || area < best_area || (area == best_area && staged < best_staged)) {
                 best_area = area; best_staged = staged; cfg = &c;
             }
         }
     }
-    p.ctiles = (l.Cin + cfg->tc - 1) / cfg->tc;
+    p.ctiles = (rows + cfg->tc - 1) / cfg->tc;
     p.ntiles = (N + cfg->tn - 1) / cfg->tn;
     p.vec_x = (l.Cin % 4 == 0) && (((uintptr_t)x & 15) == 0);
     p.vec_g = (ldg % 4 == 0) && (((uintptr_t)g & 15) == 0);
-    const long tiles = (long)l.kh * l.kw * p.ctiles * p.ntiles;
+    const long tiles = (p.im2col ? 1L : (long)l.kh * l.kw) * p.ctiles * p.ntiles;
     long rpc = 0;
     long chunks = chunks_for(p.M, tiles, &rpc, 128, 1024);
     // bound the slab: chunks * K * N floats
