@@ -39,6 +39,8 @@ def main():
     ap.add_argument("--img-size", type=int, default=300, help="300 (reference configs) or 512 (BASELINE configs[4] graph)")
     ap.add_argument("--cpu-sample", type=int, default=8, help="images per pass of the CPU baseline")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--lanes", type=int, default=2,
+                    help="batches in flight per GPU (DecoderModel.submit): 2 = step n+1's backbone overlaps step n's heads / decode / NMS; 1 = strictly one step at a time")
     ap.add_argument("--layers", action="store_true", help="also print the per-layer table to stderr")
     ap.add_argument("--train", action="store_true", help="time the training step (SURVEY 8f N1) instead of inference")
     args = ap.parse_args()
@@ -96,25 +98,37 @@ def main():
     model = get_model(hp, max_batch=B)
     weights = data_utils.synthetic_weights(model, seed=1)
     priors = bbox_utils.generate_prior_boxes(hp["feature_map_shapes"], hp["aspect_ratios"])
-    decoder_model = get_decoder_model(model, priors, hp)
+    decoder_model = get_decoder_model(model, priors, hp, lanes=args.lanes)
     x = ssd_hip.to_dev(data_utils.synthetic_images(B, hp["img_size"], seed=rank))   # resident in HBM
 
     def barrier():
         if dist is not None:
             dist.barrier()
 
-    for _ in range(max(args.warmup, 1)):
-        out = decoder_model(x)
+    # a step = one full pass (forward + decode/NMS) over one batch; with --lanes 2 consecutive steps run on
+    # two replicas of the net / two streams, so a step may start before the previous one has finished --
+    # every one of the K steps is complete at the synchronize that closes the timed region
+    for _ in range(max(args.warmup, 2 * args.lanes)):
+        out = decoder_model.submit(x)
+    decoder_model.wait()
     torch.cuda.synchronize()
     barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        out = decoder_model(x)
+        out = decoder_model.submit(x)
+    decoder_model.wait()
     torch.cuda.synchronize()
     barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    # the same K steps strictly one at a time (lane 0 only): the per-step latency view
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    for _ in range(args.steps):
+        decoder_model(x)
+    torch.cuda.synchronize()
+    sequential_ms = (time.perf_counter() - t1) / args.steps * 1e3
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -195,6 +209,9 @@ def main():
         "steps": args.steps,
         "warmup": args.warmup,
         "ms_per_step": 1e3 * elapsed / args.steps,
+        # the same K steps strictly one at a time (no step starts before the previous one has finished)
+        "ms_per_step_sequential": sequential_ms,
+        "images_per_sec_sequential": world * B / (sequential_ms * 1e-3),
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,
@@ -204,7 +221,8 @@ def main():
                        hp["img_size"], args.backbone, B, hp["img_size"], hp["img_size"],
                        (1 if args.backbone == "mobilenet_v2" else 2) if hp["img_size"] == 300 else 4),
                    "global_batch": world * B, "priors": model.num_priors, "labels": hp["total_labels"],
-                   "mean_detections_per_image": mean_det, "nms_active": mean_det > 0, "parallelism": "batch-sharded x%d, no collective" % world},
+                   "mean_detections_per_image": mean_det, "nms_active": mean_det > 0, "parallelism": "batch-sharded x%d, no collective" % world,
+                   "batches_in_flight_per_gpu": args.lanes},
         "roofline": {"bound": "mfma", "kernel": "conv_mfma_kernel + conv_wino_kernel (fp32 v_mfma_f32_16x16x4: implicit-GEMM and "
                                                  "Winograd F(2x2,3x3) tiles, all configs)",
                      # `achieved` counts ALGORITHMIC conv FLOPs (MACs x 2 of the direct

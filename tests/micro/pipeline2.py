@@ -37,5 +37,5 @@ def run(lanes, steps=40):
     print("lanes %d: %.3f ms/step  %.0f img/s" % (lanes, dt * 1e3, B / dt), flush=True)
 
 
-for lanes in (1, 2, 3, 1, 2):
+for lanes in ([int(os.environ['PIPELINE2_LANES'])] if os.environ.get('PIPELINE2_LANES') else (1, 2, 3, 1, 2)):
     run(lanes)

@@ -253,6 +253,47 @@ def test_stream_plans_agree(backbone):
                 np.testing.assert_array_equal(a, b, err_msg=str(opts))
 
 
+def test_two_lanes_match_one_lane():
+    """DecoderModel with two batches in flight (``submit`` / ``predict`` on two replicas of the net and
+    two streams): every step's detections are bitwise those of the one-step-at-a-time path, in order,
+    also after the base model's weights change (the replicas follow)."""
+    from models.decoder import get_decoder_model
+    from models.ssd_mobilenet_v2 import get_model
+    from utils import bbox_utils
+    hp = helpers.hyper_params("mobilenet_v2")
+    w = helpers.synthetic_weights("mobilenet_v2", hp)
+    m = get_model(hp, max_batch=6)
+    m.set_weights(w)
+    priors = bbox_utils.generate_prior_boxes(hp["feature_map_shapes"], hp["aspect_ratios"])
+    dm1 = get_decoder_model(m, priors, hp, lanes=1)
+    dm2 = get_decoder_model(m, priors, hp, lanes=2)
+    batches = [helpers.images(6, 300, seed=40 + i) for i in range(5)]
+    ref = [tuple(t.cpu().numpy() for t in dm1(b)) for b in batches]
+    assert any((r[2] > 0).sum() > 0 for r in ref)
+    outs = [dm2.submit(b) for b in batches]
+    dm2.wait()
+    torch.cuda.synchronize()
+    assert dm2.lane_calibration["pair"] is not None
+    for o, r in zip(outs, ref):
+        for a, b in zip(o, r):
+            np.testing.assert_array_equal(a.cpu().numpy(), b)
+    stacked = np.concatenate(batches)
+    p1 = dm1.predict(stacked, batch_size=6)
+    p2 = dm2.predict(stacked, batch_size=6)
+    for a, b in zip(p1, p2):
+        np.testing.assert_array_equal(a, b)
+    # new weights: the replicas are rebuilt from the base model
+    w2 = {k: (v * np.float32(1.01) if k.endswith("conv_label_output/bias") else v) for k, v in w.items()}
+    m.set_weights(w2)
+    ref2 = [tuple(t.cpu().numpy() for t in dm1(b)) for b in batches[:3]]
+    outs2 = [dm2.submit(b) for b in batches[:3]]
+    dm2.wait()
+    torch.cuda.synchronize()
+    for o, r in zip(outs2, ref2):
+        for a, b in zip(o, r):
+            np.testing.assert_array_equal(a.cpu().numpy(), b)
+
+
 def test_predict_ascending_batch_sizes():
     """ssd_net_predict's head-output scratch must follow a re-finalize with a larger max_batch
     (B=1 then B=8 on the same model used to overflow the B=1-sized buffers), and the captured

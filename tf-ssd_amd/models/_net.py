@@ -42,6 +42,8 @@ class SSDModel(object):
         self._max_batch = max_batch
         self._finalized_for = 0
         self._weights_set = False
+        self._weights_version = 0          # bumped by every weight change (lane replicas follow it)
+        self._options = {}
 
     def __del__(self):
         try:
@@ -67,6 +69,19 @@ class SSDModel(object):
                      "set_weights")
         self._weights_set = True
         self._finalized_for = 0
+        self._weights_version += 1
+
+    def clone(self):
+        """An independent replica (own native net: arena, scratch, streams) with the same weights, options
+        and tile tuning -- a second LANE for ``DecoderModel`` to keep two batches in flight."""
+        m = SSDModel(self.backbone, self.hyper_params, self._max_batch)
+        m.set_weights(self.get_weights())
+        for k, v in self._options.items():
+            m.set_option(k, v)
+        memo = getattr(self, "_tuning_memo", None)
+        if memo:
+            m._tuning_memo = memo
+        return m
 
     def get_weights(self):
         lib = _h.lib()
@@ -302,6 +317,7 @@ class SSDModel(object):
         _h.check(_h.lib().ssd_net_adam_step(self._net, _h.ptr(grads_flat), lr, a["b1"], a["b2"], a["eps"],
                                             float(grad_scale), _h.stream()), "ssd_net_adam_step")
         self._finalized_for = 0          # inference weights (folded BN, packed) are stale now
+        self._weights_version += 1
 
     def train_on_batch(self, images, targets, learning_rate=None):
         """Keras ``Model.train_on_batch``: one optimisation step; with torch.distributed
@@ -337,6 +353,7 @@ class SSDModel(object):
 
     def set_option(self, name, value):
         _h.check(_h.lib().ssd_net_set_option(self._net, name.encode(), int(value)), "set_option")
+        self._options[name] = int(value)
 
     def set_timing(self, enabled):
         _h.check(_h.lib().ssd_net_set_timing(self._net, int(enabled)), "set_timing")
