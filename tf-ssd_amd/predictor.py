@@ -54,7 +54,9 @@ def main(argv=None):
     ssd_model = _model_factory(args.backbone)(hyper_params, max_batch=BATCH_SIZE)
     _load_or_synthesise_weights(ssd_model, args.backbone)
     prior_boxes = bbox_utils.generate_prior_boxes(hyper_params["feature_map_shapes"], hyper_params["aspect_ratios"])
-    ssd_decoder_model = get_decoder_model(ssd_model, prior_boxes, hyper_params)
+    # two batches in flight (H2D copy + backbone of batch n+1 beside heads / decode / NMS of batch n)
+    ssd_decoder_model = get_decoder_model(ssd_model, prior_boxes, hyper_params,
+                                          lanes=int(os.environ.get("SSD_HIP_LANES", "2")))
 
     t0 = time.perf_counter()
     boxes, classes, scores = ssd_decoder_model.predict(
