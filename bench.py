@@ -222,7 +222,9 @@ def main():
                        (1 if args.backbone == "mobilenet_v2" else 2) if hp["img_size"] == 300 else 4),
                    "global_batch": world * B, "priors": model.num_priors, "labels": hp["total_labels"],
                    "mean_detections_per_image": mean_det, "nms_active": mean_det > 0, "parallelism": "batch-sharded x%d, no collective" % world,
-                   "batches_in_flight_per_gpu": args.lanes},
+                   "batches_in_flight_per_gpu": args.lanes,
+                   # which of the candidate stream pairs carries the two lanes was measured (DecoderModel)
+                   "lane_calibration": getattr(decoder_model, "lane_calibration", None)},
         "roofline": {"bound": "mfma", "kernel": "conv_mfma_kernel + conv_wino_kernel (fp32 v_mfma_f32_16x16x4: implicit-GEMM and "
                                                  "Winograd F(2x2,3x3) tiles, all configs)",
                      # `achieved` counts ALGORITHMIC conv FLOPs (MACs x 2 of the direct
