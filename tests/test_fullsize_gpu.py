@@ -6,6 +6,8 @@ by the same kernels/tiles, and an image's result does not depend on its batch ne
 and (b) size-independent properties of the outputs: bitwise determinism, batch-composition
 independence, softmax rows, and the CombinedNMS contract (sorted scores, clipped boxes,
 labels in range, zero padding, idempotence: NMS of the survivors keeps all of them)."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -292,6 +294,36 @@ def test_two_lanes_match_one_lane():
     for o, r in zip(outs2, ref2):
         for a, b in zip(o, r):
             np.testing.assert_array_equal(a.cpu().numpy(), b)
+
+
+@pytest.mark.parametrize("extra", [[], ["--lanes", "1"], ["--train"]])
+def test_bench_line_contract(extra, tmp_path):
+    """`python bench.py --steps K --warmup W` prints ONE JSON line with the driver's keys; value, ms_per_step
+    and the batch agree; `roofline` / step figures are self-consistent (small batch: this checks the
+    contract, not the performance)."""
+    import json, subprocess, sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, SSD_HIP_TUNE_CACHE=str(tmp_path))
+    cmd = [sys.executable, os.path.join(repo, "bench.py"), "--steps", "4", "--warmup", "2", "--batch", "8", "--no-cpu-baseline"] + extra
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, lines
+    r = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config"):
+        assert k in r, k
+    assert r["unit"] == "images/sec" and r["n_gpus"] == 1 and r["steps"] == 4 and r["warmup"] == 2
+    assert r["higher_is_better"] is True and r["scaling"] == "weak" and r["vs_baseline"] is None and r["dtype"] == "f32"
+    assert "workload" in r["config"] and "model" not in r["config"] and "synthetic" in r["data"]
+    assert abs(r["value"] - 8 / (r["ms_per_step"] * 1e-3)) <= 1e-6 * r["value"]
+    if "--train" not in extra:
+        ro = r["roofline"]
+        assert ro["bound"] == "mfma" and ro["unit"] == "TFLOP/s" and ro["peak"] == 157.3
+        assert abs(ro["frac"] - ro["achieved"] / ro["peak"]) < 1e-9
+        assert ro["kernel_ms_per_step"] > 0 and 0 < ro["frac_step"] < 1
+        assert r["config"]["batches_in_flight_per_gpu"] == (1 if extra else 2)
+        assert r["ms_per_step_sequential"] > 0 and r["config"]["nms_active"] is True
 
 
 def test_predict_ascending_batch_sizes():
