@@ -284,6 +284,13 @@ def test_two_lanes_match_one_lane():
     p2 = dm2.predict(stacked, batch_size=6)
     for a, b in zip(p1, p2):
         np.testing.assert_array_equal(a, b)
+    # ragged last batch (20 = 3 x 6 + 2) and a `steps` limit
+    for a, b in zip(dm1.predict(stacked[:20], batch_size=6), dm2.predict(stacked[:20], batch_size=6)):
+        assert a.shape[0] == 20
+        np.testing.assert_array_equal(a, b)
+    for a, b in zip(dm1.predict(stacked, batch_size=6, steps=2), dm2.predict(stacked, batch_size=6, steps=2)):
+        assert a.shape[0] == 12
+        np.testing.assert_array_equal(a, b)
     # new weights: the replicas are rebuilt from the base model
     w2 = {k: (v * np.float32(1.01) if k.endswith("conv_label_output/bias") else v) for k, v in w.items()}
     m.set_weights(w2)
