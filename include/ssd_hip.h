@@ -240,6 +240,15 @@ int ssd_net_finalize(ssd_net* net, int max_batch);
  * set installs a table that the next finalize uses instead of re-tuning (if complete/valid). */
 long ssd_net_get_tuning(const ssd_net* net, char* buf, size_t cap);
 int ssd_net_set_tuning(ssd_net* net, const char* text);
+/* How the last finalize chose its kernels: *from_table = conv layers taken from preset lines,
+ * *timed = choices timed on the device (conv layers + whole-image blocks + launch mode).  timed == 0
+ * means the table was complete: nothing depends on timing noise, results are reproducible bit for bit
+ * across processes.  (The reference's Keras graph is deterministic in which kernels it runs; this is
+ * the counterpart guarantee -- models/ssd_mobilenet_v2.py:7-35.) */
+int ssd_net_tuning_stats(const ssd_net* net, int* from_table, int* timed);
+/* sha256 (first 16 hex digits) of the kernel sources this library was built from (csrc/build.sh);
+ * shipped tuning tables record the build they were measured on. */
+const char* ssd_build_id(void);
 int ssd_net_num_priors(const ssd_net* net);
 int ssd_net_feature_map_size(const ssd_net* net, int level);
 
@@ -323,6 +332,11 @@ int ssd_net_train_forward_backward(ssd_net* net, const float* image_dev, int B,
 int ssd_net_adam_step(ssd_net* net, const float* grads_flat_dev, float lr, float beta1, float beta2,
                       float eps, float grad_scale, void* stream);
 long ssd_net_train_steps(const ssd_net* net);
+/* Sum of the layers' regularisation losses at the current weights: 5e-4 * sum(kernel^2) over VGG16's
+ * backbone / extra convs (reference models/ssd_vgg16.py:44-45), 0 for MobileNetV2.  Keras adds this term to
+ * the `loss` and `val_loss` that fit() logs and ModelCheckpoint(save_best_only) monitors (trainer.py:56-63).
+ * Synchronous (legacy stream, one float copied to the host). */
+int ssd_net_regularization_loss(ssd_net* net, float* host_out);
 /* Debug / parity hook: copy a buffer of the last training forward/backward (batch B) to the host:
  * "probs", "deltas", "grad_logits", "grad_deltas", "<tensor>", "grad:<tensor>", "pre:<layer>",
  * "mean:<layer>", "var:<layer>".  Returns the element count (host_out NULL: query). */

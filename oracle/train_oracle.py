@@ -4,7 +4,8 @@ TRAINING mode (BatchNorm on batch statistics, Keras momentum 0.999 / eps 1e-3 mo
 update), the torch restatement of the loss (oracle/loss_oracle.py) and a NumPy Adam in TF's
 ApplyAdam form.  Only tests/ may import this module.  PARITY UNPINNED (no TensorFlow here): what
 Keras / TF do in ``fit`` is restated from source knowledge ([3P]): fused BatchNorm normalises with
-the biased batch variance and Keras removes Bessel's correction before the moving-average update;
+the biased batch variance while the moving variance follows the Bessel-corrected one (the fused op's
+second output; Keras' BatchNormalization keeps it: ``_bessels_correction_test_only = True``);
 ReluGrad / Relu6Grad pass the gradient strictly inside (0, 6); Adam eps 1e-7."""
 import numpy as np
 import torch
@@ -81,7 +82,8 @@ class TrainOps(tg.TorchOps):
     def batch_norm(x, gamma, beta, mean, var, eps=no.BN_EPS):
         mu = x.mean(dim=(0, 2, 3))
         va = ((x - mu.view(1, -1, 1, 1)) ** 2).mean(dim=(0, 2, 3))           # biased
-        TrainOps.moving.append((mean, mu.detach(), var, va.detach()))
+        m = x.numel() // x.shape[1]
+        TrainOps.moving.append((mean, mu.detach(), var, va.detach() * np.float32(m / max(m - 1, 1))))
         xh = (x - mu.view(1, -1, 1, 1)) * torch.rsqrt(va + eps).view(1, -1, 1, 1)
         return xh * gamma.view(1, -1, 1, 1) + beta.view(1, -1, 1, 1)
 

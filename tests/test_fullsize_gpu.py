@@ -359,8 +359,9 @@ def test_predict_ascending_batch_sizes():
     ref = get_model(hp, max_batch=8)
     ref.set_weights(w)
     rdm = get_decoder_model(ref, priors, hp)
-    for a, b in zip(eight, rdm.predict_on_batch(x)):      # a second net autotunes on its own: other tiles / split-K
-        assert np.abs(a - b).max() <= 1e-5
+    for a, b in zip(eight, rdm.predict_on_batch(x)):      # same shapes -> same kernel table (shipped / memo) -> same bits
+        np.testing.assert_array_equal(a, b)
+    assert ref.get_tuning() == m.get_tuning()
     assert (eight[2] > 0).sum() > 0
     for a, b in zip(back, [r[:1] for r in eight]):              # same tiles at any batch? at least close
         assert np.abs(a - b).max() <= 1e-4

@@ -207,6 +207,19 @@ def test_native_graph_matches_oracle_and_published_counts(backbone, n_priors):
     bad["feature_map_shapes"] = list(hp["feature_map_shapes"][:-1]) + [7]
     with pytest.raises(ValueError):
         SSDModel(backbone, bad)
+    # checkpoint layer order = Keras' model.layers (depth-sorted): every weighted layer once, the
+    # chain first, ALL label heads before ALL box heads, l2_normalization tied with (and before) conv11_2
+    order = m.layer_order()
+    table = []
+    for n in names:
+        if n.rsplit("/", 1)[0] not in table:
+            table.append(n.rsplit("/", 1)[0])
+    assert sorted(order) == sorted(table) and len(set(order)) == len(order)
+    assert order[-12:] == ["%d_conv_label_output" % i for i in range(1, 7)] + ["%d_conv_boxes_output" % i for i in range(1, 7)]
+    chain = [l for l in table if not l[0].isdigit() and l != "l2_normalization"]
+    assert [l for l in order[:-12] if l != "l2_normalization"] == chain
+    if backbone == "vgg16":
+        assert order.index("l2_normalization") == order.index("conv11_2") - 1 == order.index("conv11_1") + 1
 
 
 def test_u1_box_helpers_product_vs_oracle():

@@ -310,6 +310,12 @@ def test_train_step_vgg16_matches_autograd_oracle():
         rg = ref["grads"][name]
         assert np.linalg.norm(got - rg) <= 2e-3 * np.linalg.norm(rg) + 1e-6, name
     assert max(errs)[0] <= 2e-2, max(errs)
+    # Keras adds sum(model.losses) = 5e-4 * sum(kernel^2) over the regularised convs to `loss` / `val_loss`
+    reg = sum(5e-4 * float((np.asarray(v, np.float64) ** 2).sum()) for k, v in w.items()
+              if k.endswith("/kernel") and not k[0].isdigit())
+    assert reg > 0 and abs(m.regularization_loss() - reg) <= 1e-5 * reg
+    tot, lm, cm = m.evaluate_on_batch(x, (yd, yl))
+    assert abs(tot - (lm + cm + reg)) <= 1e-5 * tot
     m.apply_gradients(m._grads, learning_rate=LR)
     loc2, conf2, _ = m.forward_backward(x, yd, yl)
     assert float((loc2 + conf2).mean()) < float((loc + conf).mean())

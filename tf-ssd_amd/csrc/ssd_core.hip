@@ -15,7 +15,9 @@ void set_error(const char* fmt, ...) {
 
 extern "C" {
 
-const char* ssd_version(void) { return "ssd_hip 0.2 (gfx950)"; }
+const char* ssd_version(void) { return "ssd_hip 0.3 (gfx950)"; }
+#include "build/build_id.h"
+const char* ssd_build_id(void) { return SSD_BUILD_ID; }
 
 const char* ssd_last_error(void) { return ssd::g_err; }
 

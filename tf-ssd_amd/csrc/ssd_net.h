@@ -104,6 +104,9 @@ struct ssd_net {
     int scratch_batch = 0;          // batch capacity deltas/probs were allocated for
     // optional per-layer hipEvent timing of forward()/predict() (bench.py roofline leg)
     std::map<std::string, std::pair<std::string, int>> preset;   // layer -> (config name, split_k)
+    int n_preset = 0;               // conv layers the last finalize took from preset lines
+    int n_autotuned = 0;            // choices the last finalize timed on the device (0 = fully reproducible table)
+    bool launch_raced = false;      // the graph-replay / direct-launch choice was made by a race or a preset line
     // hipGraph replay of a whole forward/predict step, keyed by every pointer baked into it
     bool use_graph = true;
     bool use_graph_auto = true;     // finalize races graph replay against direct launches (until "use_graph" is set explicitly)

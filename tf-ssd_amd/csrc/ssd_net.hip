@@ -500,6 +500,7 @@ static int tune_image_blocks(ssd_net& net, int B, hipStream_t st) {
         if (f.kind != LK_FUSED || f.f_type != 0) continue;
         const FusedBlockParams p = fused_params(net, f, B);
         if (fused_block_supported(p) || !image_block_supported(p)) { f.img_choice = 0; continue; }
+        if (f.img_choice >= 0) continue;        // preset line
         float ms[2] = {1e30f, 1e30f};
         for (int choice = 0; choice < 2 && !rc; ++choice) {
             f.img_choice = choice;
@@ -551,6 +552,7 @@ static int autotune(ssd_net& net, int B, hipStream_t st) {
     const bool dbg_sync = getenv("SSD_HIP_DEBUG_SYNC") != nullptr;   // name the launch a GPU fault belongs to
     for (auto& l : net.layers) {
         if (l.kind != LK_CONV) continue;
+        if (l.cfg >= 0) continue;           // chosen by a valid preset line (ssd_net_set_tuning)
         const float* in = net.tensors[l.in].dev;
         float* out = l.out >= 0 ? net.tensors[l.out].dev : nullptr;
         const float* res = l.res >= 0 ? net.tensors[l.res].dev : nullptr;
@@ -736,6 +738,15 @@ int ssd_net_get_param(const ssd_net* net, const char* name, float* host_out, siz
 // Skipped once "use_graph" was set explicitly.
 static int tune_launch_mode(ssd_net* net, int B) {
     if (!net->use_graph_auto || net->timing) return SSD_OK;
+    {
+        auto it = net->preset.find("__launch");          // "__launch graph 0|1": the recorded outcome of this race
+        if (it != net->preset.end() && it->second.first == "graph") {
+            net->use_graph = it->second.second != 0;
+            net->launch_raced = true;
+            return SSD_OK;
+        }
+    }
+    ++net->n_autotuned;
     const size_t n_img = (size_t)B * net->img_size * net->img_size * 3;
     ScopedDev img, del, prb;
     SSD_HIP(hipMalloc((void**)&img.p, n_img * sizeof(float)));
@@ -770,6 +781,7 @@ static int tune_launch_mode(ssd_net* net, int B) {
     // the two are within ~1 % at B=64 and direct launches measured faster on real batches (heads overlap the
     // backbone earlier): replay only where it is clearly ahead (small batches, launch-bound hosts)
     net->use_graph = rc ? true : ms[1] < ms[0] * 0.99f;
+    net->launch_raced = !rc;
     if (getenv("SSD_HIP_DEBUG_TUNE"))
         fprintf(stderr, "[ssd] launch mode race at B=%d: direct %.4f ms, graph replay %.4f ms per forward -> %s\n", B, ms[0] / 6,
                 ms[1] / 6, net->use_graph ? "replay" : "direct");
@@ -915,23 +927,28 @@ int ssd_net_finalize(ssd_net* net, int max_batch) {
     net->max_batch = max_batch;
     // pick tile configurations on the device
     for (auto& l : net->layers) { l.cfg = -1; l.split_k = 1; }
-    // a complete, valid preset (ssd_net_set_tuning) replaces the on-device autotune
-    bool preset_ok = !net->preset.empty();
+    // preset lines (ssd_net_set_tuning) replace the on-device autotune LAYER BY LAYER: a layer whose line
+    // is missing or names a configuration that cannot run it here is timed on the device, the others are
+    // not -- a complete table means no timing at all and therefore the same kernels (and the same bits)
+    // in every process that loads it
     size_t ws_need = 0;
+    int n_tuned = 0, n_preset = 0;
     for (auto& l : net->layers) {
-        if (l.kind != LK_CONV || !preset_ok) continue;
+        if (l.kind != LK_CONV) continue;
         auto it = net->preset.find(l.name);
-        if (it == net->preset.end()) { preset_ok = false; break; }
+        if (it == net->preset.end()) { ++n_tuned; continue; }
         int cfg = -1;
         for (int c = 0; c < conv_num_configs(); ++c)
             if (it->second.first == conv_config_name(c)) cfg = c;
-        if (cfg < 0) { preset_ok = false; break; }
+        if (cfg < 0) { ++n_tuned; continue; }
         l.cfg = cfg;
         l.split_k = it->second.second;
         ConvParams p = layer_conv_params(*net, l, max_batch, net->tensors[l.in].dev,
                                          l.out >= 0 ? net->tensors[l.out].dev : nullptr, nullptr,
                                          net->arena, net->arena);
-        if (!conv_config_valid(cfg, p)) { preset_ok = false; break; }
+        const bool split_ok = l.split_k == 1 || conv_k_tiles(cfg, p) >= l.split_k;
+        if (l.split_k < 1 || !split_ok || !conv_config_valid(cfg, p)) { l.cfg = -1; l.split_k = 1; ++n_tuned; continue; }
+        ++n_preset;
         if (l.split_k > 1) ws_need = std::max(ws_need, (size_t)l.split_k * p.M * p.Cout);
     }
     bool image_preset_ok = true;
@@ -945,17 +962,15 @@ int ssd_net_finalize(ssd_net* net, int max_batch) {
         f.img_choice = it->second.second ? 1 : 0;
     }
     int rc = SSD_OK;
-    if (preset_ok) {
-        if (ws_need > net->splitk_floats) {
-            if (net->splitk_ws) (void)hipFree(net->splitk_ws);
-            net->splitk_ws = nullptr;
-            SSD_HIP(hipMalloc((void**)&net->splitk_ws, ws_need * sizeof(float)));
-            net->splitk_floats = ws_need;
-        }
-    } else {
-        for (auto& l : net->layers) { l.cfg = -1; l.split_k = 1; }
-        rc = autotune(*net, max_batch, st);
+    if (ws_need > net->splitk_floats) {
+        if (net->splitk_ws) (void)hipFree(net->splitk_ws);
+        net->splitk_ws = nullptr;
+        SSD_HIP(hipMalloc((void**)&net->splitk_ws, ws_need * sizeof(float)));
+        net->splitk_floats = ws_need;
     }
+    net->n_autotuned = n_tuned;
+    net->n_preset = n_preset;
+    if (n_tuned) rc = autotune(*net, max_batch, st);
     if (rc) return rc;
     // every split-K layer gets its own slab (layers on different streams may overlap)
     {
@@ -983,9 +998,10 @@ int ssd_net_finalize(ssd_net* net, int max_batch) {
         for (auto& l : net->layers)
             if (!l.ev_ready) SSD_HIP(hipEventCreateWithFlags(&l.ev_ready, hipEventDisableTiming));
     }
-    if (!preset_ok || !image_preset_ok) {
+    if (!image_preset_ok) {
         rc = tune_image_blocks(*net, max_batch, st);
         if (rc) return rc;
+        ++net->n_autotuned;
     }
     SSD_HIP(hipDeviceSynchronize());
     net->drop_graphs();
@@ -1006,8 +1022,17 @@ long ssd_net_get_tuning(const ssd_net* net, char* buf, size_t cap) {
             if (!fused_block_supported(p) && image_block_supported(p))
                 out += l.name + " image " + std::to_string(l.img_choice) + "\n";
         }
+    if (net->finalized && net->use_graph_auto && net->launch_raced)
+        out += std::string("__launch graph ") + (net->use_graph ? "1" : "0") + "\n";
     if (buf && cap > out.size()) memcpy(buf, out.c_str(), out.size() + 1);
     return (long)out.size();
+}
+
+int ssd_net_tuning_stats(const ssd_net* net, int* from_table, int* timed) {
+    SSD_CHECK_ARG(net != nullptr, "ssd_net_tuning_stats: net is NULL");
+    if (from_table) *from_table = net->n_preset;
+    if (timed) *timed = net->n_autotuned;
+    return SSD_OK;
 }
 
 int ssd_net_set_tuning(ssd_net* net, const char* text) {
@@ -1022,7 +1047,10 @@ int ssd_net_set_tuning(ssd_net* net, const char* text) {
         pos = e + 1;
         char name[128], cfg[128];
         int split = 1;
-        if (sscanf(line.c_str(), "%127s %127s %d", name, cfg, &split) == 3 && split >= (std::string(cfg) == "image" ? 0 : 1) && split <= 64)
+        if (line.empty() || line[0] == '#') continue;
+        const bool flag = sscanf(line.c_str(), "%127s %127s %d", name, cfg, &split) == 3 &&
+                          (std::string(cfg) == "image" || std::string(cfg) == "graph");
+        if (sscanf(line.c_str(), "%127s %127s %d", name, cfg, &split) == 3 && split >= (flag ? 0 : 1) && split <= 64)
             net->preset[name] = {cfg, split};
     }
     net->finalized = false;

@@ -95,12 +95,15 @@ __global__ __launch_bounds__(256) void add_kernel(float* __restrict__ dst, const
 }
 
 // Keras moving average: var -= (var - value) * (1 - momentum)
+// (the fused BatchNorm op hands Keras the Bessel-corrected batch variance, var * M / (M - 1), and Keras'
+// BatchNormalization keeps it for the moving average -- `_bessels_correction_test_only` -- while the
+// normalisation and the backward use the biased one)
 __global__ void moving_update_kernel(float* mm, float* mv, const float* mean, const float* var, const int C,
-                                     const float one_minus_momentum) {
+                                     const float one_minus_momentum, const float bessel) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c < C) {
         mm[c] -= (mm[c] - mean[c]) * one_minus_momentum;
-        mv[c] -= (mv[c] - var[c]) * one_minus_momentum;
+        mv[c] -= (mv[c] - var[c] * bessel) * one_minus_momentum;
     }
 }
 
@@ -306,7 +309,7 @@ __global__ __launch_bounds__(256) void col_finalize_kernel(const float* __restri
                                                           const float scale, float* out1, float* out2, const int mode,
                                                           const float eps, const float* shift = nullptr, float* out3 = nullptr,
                                                           float* mm = nullptr, float* mv = nullptr,
-                                                          const float one_minus_momentum = 0.f) {
+                                                          const float one_minus_momentum = 0.f, const float bessel = 1.f) {
     // block = 16 columns x 16 chunk lanes (lane k sums chunks k, k+16, ... in order; the 16 lane
     // sums are combined in a fixed order: deterministic).  The data is tiny; the kernel is latency
     // bound, hence many short dependent chains instead of few long ones.
@@ -337,7 +340,7 @@ __global__ __launch_bounds__(256) void col_finalize_kernel(const float* __restri
         out2[c] = var;
         out3[c] = 1.0f / sqrtf(var + eps);
         mm[c] -= (mm[c] - mean) * one_minus_momentum;       // Keras moving average: v -= (v - value) * (1 - momentum)
-        mv[c] -= (mv[c] - var) * one_minus_momentum;
+        mv[c] -= (mv[c] - var * bessel) * one_minus_momentum;   // Bessel-corrected value, see moving_update_kernel
         return;
     }
     if (out1) out1[c] = s1;
@@ -787,6 +790,26 @@ __global__ __launch_bounds__(256) void axpy_kernel(float* __restrict__ g, const 
     for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < n; e += (long)gridDim.x * 256) g[e] += coef * w[e];
 }
 
+// partial[blockIdx.x] = sum of w^2 over this block's grid-stride slice (fixed slices, fixed in-block tree:
+// deterministic); reg_finalize sums the partials in order and applies the l2 factor
+__global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ w, const long n, float* __restrict__ partial) {
+    __shared__ float sh[256];
+    float s = 0.f;
+    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < n; e += (long)gridDim.x * 256) s += w[e] * w[e];
+    sh[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) sh[threadIdx.x] += sh[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) partial[blockIdx.x] = sh[0];
+}
+__global__ void reg_finalize_kernel(const float* __restrict__ partial, const int n, const float l2, float* out) {
+    double s = 0.0;
+    for (int i = 0; i < n; ++i) s += (double)partial[i];
+    *out = (float)(s * (double)l2);
+}
+
 // ------------------------------------------------------------------ Adam (TF training_ops.ApplyAdam form)
 // m += (g - m)(1 - b1); v += (g^2 - v)(1 - b2); var -= alpha * m / (sqrt(v) + eps),
 // alpha = lr * sqrt(1 - b2^t) / (1 - b1^t); g = grad * grad_scale (+ l2 * var where l2mask set)
@@ -935,19 +958,20 @@ static int col_finalize(ssd_train_state& s, long chunks, int C, float scale, flo
     return SSD_OK;
 }
 
-// batch statistics of pre [M][C] -> mean, var (biased), istd, and the moving-average update: one
+// batch statistics of pre [M][C] -> mean, var (biased), istd, and the moving-average update (unbiased variance): one
 // pass over `pre` (shifted sums, see col_reduce4_kernel) + one finalize launch
 static int bn_stats(ssd_train_state& s, TrainLayer& t, long M, int C, float* moving_mean, float* moving_var,
                     hipStream_t st) {
     RedParams p{};
     p.a = t.pre; p.M = M; p.C = C; p.lda = C;
     long chunks = 0;
+    const float bessel = M > 1 ? (float)((double)M / (double)(M - 1)) : 1.0f;
     if (C % 4 == 0 && ((uintptr_t)t.pre & 15) == 0) {
         int rc = col_reduce<RED_STATS>(s, p, &chunks, st);
         if (rc) return rc;
         hipLaunchKernelGGL(col_finalize_kernel, dim3((C + 15) / 16), dim3(256), 0, st, s.partial, (int)chunks, C,
                            1.0f / (float)M, t.mean, t.var, 2, kBnEps, t.pre, t.istd, moving_mean, moving_var,
-                           1.0f - kBnMomentum);
+                           1.0f - kBnMomentum, bessel);
         SSD_LAUNCH_CHECK();
         return SSD_OK;
     }
@@ -959,7 +983,7 @@ static int bn_stats(ssd_train_state& s, TrainLayer& t, long M, int C, float* mov
     if (!rc) rc = col_finalize(s, chunks, C, 1.0f / (float)M, t.var, t.istd, 1, st);
     if (rc) return rc;
     hipLaunchKernelGGL(moving_update_kernel, dim3((C + 255) / 256), dim3(256), 0, st, moving_mean, moving_var, t.mean, t.var, C,
-                       1.0f - kBnMomentum);
+                       1.0f - kBnMomentum, bessel);
     SSD_LAUNCH_CHECK();
     return SSD_OK;
 }
@@ -1492,6 +1516,30 @@ int ssd_net_train_forward_backward(ssd_net* net, const float* image_dev, int B, 
                                w.dev, (long)w.count, 2.0f * 5e-4f);
             SSD_LAUNCH_CHECK();
         }
+    return SSD_OK;
+}
+
+// Sum of the layers' regularisation losses, the term Keras adds to `loss` / `val_loss` beside the compiled
+// losses: VGG16's kernel_regularizer=l2(5e-4) on every backbone / extra conv (models/ssd_vgg16.py:44-45),
+// nothing for MobileNetV2 (keras-applications builds it without regularisers; models/header.py:60-61 has none).
+int ssd_net_regularization_loss(ssd_net* net, float* host_out) {
+    SSD_CHECK_ARG(net && host_out, "ssd_net_regularization_loss: NULL argument");
+    *host_out = 0.f;
+    if (net->backbone != SSD_VGG16) return SSD_OK;
+    std::vector<const Param*> ws;
+    for (const auto& l : net->layers)
+        if (l.kind == LK_CONV && !l.head_kind && l.p_kernel >= 0 && net->params[l.p_kernel].dev) ws.push_back(&net->params[l.p_kernel]);
+    if (ws.empty()) return SSD_OK;
+    constexpr int kBlocks = 64;
+    float* scratch = nullptr;
+    SSD_HIP(hipMalloc((void**)&scratch, (ws.size() * kBlocks + 1) * sizeof(float)));
+    for (size_t i = 0; i < ws.size(); ++i)
+        hipLaunchKernelGGL(sumsq_kernel, dim3(kBlocks), dim3(256), 0, nullptr, ws[i]->dev, (long)ws[i]->count, scratch + i * kBlocks);
+    hipLaunchKernelGGL(reg_finalize_kernel, dim3(1), dim3(1), 0, nullptr, scratch, (int)(ws.size() * kBlocks), 5e-4f,
+                       scratch + ws.size() * kBlocks);
+    const hipError_t e = hipMemcpy(host_out, scratch + ws.size() * kBlocks, sizeof(float), hipMemcpyDeviceToHost);
+    (void)hipFree(scratch);
+    SSD_HIP(e);
     return SSD_OK;
 }
 

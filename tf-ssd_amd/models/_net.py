@@ -10,6 +10,9 @@ import torch
 
 import ssd_hip as _h
 
+# options that change which kernel configurations finalize may choose (the memo is per option set)
+_TABLE_OPTIONS = ("use_wino",)
+
 
 class SSDModel(object):
     """Callable like the Keras model the reference builds: ``model(images) ->
@@ -78,9 +81,10 @@ class SSDModel(object):
         m.set_weights(self.get_weights())
         for k, v in self._options.items():
             m.set_option(k, v)
-        memo = getattr(self, "_tuning_memo", None)
-        if memo:
-            m._tuning_memo = memo
+        if self._finalized_for:
+            m._tuning_explicit = self.get_tuning()     # the replica runs exactly the parent's kernels
+        elif getattr(self, "_tuning_explicit", None) is not None:
+            m._tuning_explicit = self._tuning_explicit
         return m
 
     def get_weights(self):
@@ -94,13 +98,28 @@ class SSDModel(object):
         return out
 
     def layer_order(self):
-        """Layer names in parameter-table (= Keras model) order."""
-        out = []
+        """Weighted layers in the order of Keras' ``model.layers`` -- what ``load_weights(by_name=False)``
+        (the reference's call, trainer.py:48 / predictor.py:46) pairs position by position with the
+        file's ``layer_names``.  [3P, restated from the Keras functional-API source, not executable here]
+        ``Network._map_graph_network`` sorts layers by DEPTH (longest path to an output, descending) and
+        breaks ties by the pre-order of a depth-first walk from ``outputs = [pred_deltas, pred_labels]``
+        (models/ssd_*.py: ``Model(inputs, [pred_deltas, pred_labels])``; models/header.py:60-66):
+        backbone + extras are one chain (depth strictly decreasing); ``{i}_conv_label_output`` sits at depth
+        2 (-> labels_head -> conf), ``{i}_conv_boxes_output`` at depth 1 (-> loc), so ALL label convs come
+        before ALL box convs; VGG16's ``l2_normalization`` (depth 3, reached first in the walk through
+        1_conv_boxes_output) ties with ``conv11_2`` and precedes it.  Loading ``by_name=True`` on the
+        Keras side does not depend on any of this."""
+        table = []
         for name, _ in self.param_specs:
             l = name.rsplit("/", 1)[0]
-            if l not in out:
-                out.append(l)
-        return out
+            if l not in table:
+                table.append(l)
+        chain = [l for l in table if not l[0].isdigit() and l != "l2_normalization"]
+        if "l2_normalization" in table:
+            chain.insert(chain.index("conv11_2"), "l2_normalization")
+        labels = sorted((l for l in table if l.endswith("_conv_label_output")), key=lambda n: int(n.split("_")[0]))
+        boxes = sorted((l for l in table if l.endswith("_conv_boxes_output")), key=lambda n: int(n.split("_")[0]))
+        return chain + labels + boxes
 
     def save_weights(self, path):
         """Keras ``Model.save_weights`` (reference trainer.py:65 via ModelCheckpoint,
@@ -149,39 +168,60 @@ class SSDModel(object):
             raise RuntimeError("model has no weights: call set_weights()/load_weights() first")
         want = max(B, self._max_batch or 0)
         if self._finalized_for < want:
-            lib = _h.lib()
-            # optional tuning cache (env SSD_HIP_TUNE_CACHE = directory): skip the on-device
-            # autotune when a table for this (backbone, size, labels, batch) was saved before
-            cache = os.environ.get("SSD_HIP_TUNE_CACHE")
-            path = None
-            if cache:
-                # the table is only valid for this library build, this device and this anchor
-                # configuration (head widths follow len(aspect_ratios))
-                ars = "-".join(str(len(a)) for a in self.hyper_params["aspect_ratios"])
-                # (the marketing name is not stable -- it reads "" under rocprofv3 -- the ISA name is)
-                props = torch.cuda.get_device_properties(torch.cuda.current_device())
-                dev = "%s_cu%d" % (str(getattr(props, "gcnArchName", "gpu")).split(":")[0], props.multi_processor_count)
-                ver = lib.ssd_version().decode().replace(" ", "_").replace("/", "_")
-                path = os.path.join(cache, "%s_%d_%d_a%s_b%d_%s_%s.tune" % (
-                    self.backbone, self.img_size, self.total_labels, ars, want, dev, ver))
-                if os.path.exists(path):
-                    with open(path, "rb") as f:
-                        _h.check(lib.ssd_net_set_tuning(self._net, f.read()), "ssd_net_set_tuning")
-            # a re-finalize of the same shapes (new weights: training, load_weights) reuses the
-            # table the first finalize tuned instead of timing every candidate again
-            memo = getattr(self, "_tuning_memo", None)
-            if memo and memo[0] == want and not (path and os.path.exists(path)):
-                _h.check(lib.ssd_net_set_tuning(self._net, memo[1].encode()), "ssd_net_set_tuning")
-            _h.check(lib.ssd_net_finalize(self._net, want), "ssd_net_finalize")
-            self._finalized_for = want
-            self._tuning_memo = (want, self.get_tuning())
-            if path and not os.path.exists(path):
-                # one process per GPU may race on the same file: write privately, publish atomically
-                os.makedirs(cache, exist_ok=True)
-                tmp = "%s.%d.tmp" % (path, os.getpid())
-                with open(tmp, "w") as f:
-                    f.write(self.get_tuning())
-                os.replace(tmp, path)
+            self._finalize(want)
+
+    def _finalize(self, want):
+        """``ssd_net_finalize`` with the kernel-choice table resolved as tuning.py describes (explicit
+        table > SSD_HIP_TUNE_CACHE > shipped table > process memo > on-device autotune on a miss)."""
+        import tuning
+        lib = _h.lib()
+        key = tuning.table_key(self.backbone, self.img_size, self.total_labels, self.hyper_params["aspect_ratios"], want)
+        opts = tuning.options_key({k: v for k, v in self._options.items() if k in _TABLE_OPTIONS})
+        source, text, path = "autotune", None, None
+        explicit = getattr(self, "_tuning_explicit", None)
+        cache = os.environ.get("SSD_HIP_TUNE_CACHE")
+        if cache:
+            # only valid for this library build and this device (the marketing name is not stable -- it
+            # reads "" under rocprofv3 -- the ISA name is)
+            props = torch.cuda.get_device_properties(torch.cuda.current_device())
+            dev = "%s_cu%d" % (str(getattr(props, "gcnArchName", "gpu")).split(":")[0], props.multi_processor_count)
+            path = os.path.join(cache, "%s_%s_%s%s.tune" % (key, dev, lib.ssd_build_id().decode(), ("_" + opts) if opts else ""))
+        if explicit is not None:
+            source, text = "explicit", explicit
+        elif path and os.path.exists(path):
+            with open(path) as f:
+                source, text = "cache", f.read()
+        elif not opts and tuning.load_shipped(key) is not None:
+            source, text = "shipped", tuning.load_shipped(key)
+        elif tuning.memo_get(key, opts) is not None:
+            source, text = "memo", tuning.memo_get(key, opts)
+        _h.check(lib.ssd_net_set_tuning(self._net, tuning.body(text or "").encode()), "ssd_net_set_tuning")
+        if text is None and os.environ.get("SSD_HIP_AUTOTUNE", "1") == "0":
+            raise RuntimeError("no tuning table for %s and SSD_HIP_AUTOTUNE=0 (tables: %s)" % (key, tuning.SHIPPED_DIR))
+        _h.check(lib.ssd_net_finalize(self._net, want), "ssd_net_finalize")
+        self._finalized_for = want
+        a, b = ctypes.c_int(0), ctypes.c_int(0)
+        _h.check(lib.ssd_net_tuning_stats(self._net, ctypes.byref(a), ctypes.byref(b)), "ssd_net_tuning_stats")
+        table = self.get_tuning()
+        hdr = tuning.header(text or "")
+        self.tuning_info = {"key": key, "source": source, "table_sha16": tuning.sha16(table), "layers_from_table": a.value,
+                            "choices_timed_on_device": b.value, "reproducible": b.value == 0,
+                            "table_build": hdr.get("build"), "this_build": lib.ssd_build_id().decode()}
+        if explicit is None:
+            tuning.memo_put(key, opts, table)
+        if path and not os.path.exists(path):
+            # one process per GPU may race on the same file: write privately, publish atomically
+            os.makedirs(cache, exist_ok=True)
+            tmp = "%s.%d.tmp" % (path, os.getpid())
+            with open(tmp, "w") as f:
+                f.write(tuning.with_header(table, key=key, build=lib.ssd_build_id().decode()))
+            os.replace(tmp, path)
+
+    def set_tuning(self, text):
+        """Pin the kernel choices (a table from ``get_tuning()`` of another instance, or a file): the next
+        finalize uses it instead of the shipped table / autotune.  ``None`` returns to the default."""
+        self._tuning_explicit = text
+        self._finalized_for = 0
 
     def __call__(self, images):
         x = _h.to_dev(images)
@@ -323,13 +363,24 @@ class SSDModel(object):
         """Keras ``Model.train_on_batch``: one optimisation step; with torch.distributed
         initialised, gradients are summed over the ranks (RCCL all-reduce over xGMI) and
         averaged (batch data-parallel).  Returns (loss, loc_loss, conf_loss) host
-        floats of THIS rank's batch (Keras logs the batch means)."""
+        floats of THIS rank's batch (Keras logs the batch means; ``loss`` includes the regularisation term,
+        the two components do not)."""
         import parallel
         loc, conf, g = self.forward_backward(images, targets[0], targets[1])
+        reg = self.regularization_loss()               # at the weights this batch was evaluated with, like Keras
         world = parallel.allreduce_gradients(g)
         self.apply_gradients(g, learning_rate, 1.0 / world)
         lm, cm = float(loc.mean().item()), float(conf.mean().item())
-        return lm + cm, lm, cm
+        return lm + cm + reg, lm, cm
+
+    def regularization_loss(self):
+        """Keras' ``sum(model.losses)``: l2(5e-4) over VGG16's regularised kernels, 0 for MobileNetV2 -- part
+        of the ``loss`` / ``val_loss`` Keras logs and checkpoints on (reference models/ssd_vgg16.py:44-45)."""
+        if self.backbone != "vgg16":
+            return 0.0
+        out = ctypes.c_float(0.0)
+        _h.check(_h.lib().ssd_net_regularization_loss(self._net, ctypes.byref(out)), "regularization_loss")
+        return float(out.value)
 
     def train_fetch(self, what, B):
         """Buffer of the last training forward/backward (debug / parity tests)."""
@@ -349,7 +400,7 @@ class SSDModel(object):
         cl = CustomLoss(getattr(self, "_neg_pos_ratio", 3.0), getattr(self, "_loc_alpha", 1.0))
         lm = float(cl.loc_loss_fn(targets[0], d).mean().item())
         cm = float(cl.conf_loss_fn(targets[1], p).mean().item())
-        return lm + cm, lm, cm
+        return lm + cm + self.regularization_loss(), lm, cm
 
     def set_option(self, name, value):
         _h.check(_h.lib().ssd_net_set_option(self._net, name.encode(), int(value)), "set_option")

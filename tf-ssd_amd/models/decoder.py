@@ -84,9 +84,11 @@ class DecoderModel(object):
         # head convs overlap the backbone of step n + 1 (measured at B=64: 1.95 -> 1.73-1.79 ms per step
         # with 2 lanes, nothing with graph replay, 1.83 with 3).  ``__call__`` / ``predict_on_batch`` stay
         # on lane 0 and on the caller's stream.
+        # Every lane is a REPLICA: the base model itself is never reconfigured (it keeps its launch mode for
+        # ``__call__`` / ``predict_on_batch``).
         self.lanes = max(1, int(lanes))
-        self._lane_models = [base_model]
-        self._lane_streams = [None]
+        self._lane_models = []
+        self._lane_streams = []
         self._lane_version = None
         self._next_lane = 0
         self._lanes_calibrated = False
@@ -95,9 +97,7 @@ class DecoderModel(object):
         """(model, stream) of lane i; replicas are (re)built when the base model's weights changed."""
         ver = getattr(self.base_model, "_weights_version", 0)
         if self._lane_version != ver:
-            self._lane_models = [self.base_model]          # replicas are rebuilt; the (calibrated) streams stay
-            if self._lane_streams[0] is None:
-                self._lane_streams[0] = torch.cuda.Stream()
+            self._lane_models = []                         # replicas are rebuilt; the (calibrated) streams stay
             self._lane_version = ver
         while len(self._lane_models) <= i:
             m = self.base_model.clone()
@@ -163,12 +163,9 @@ class DecoderModel(object):
         if self.lanes == 1 or not hasattr(self.base_model, "predict_on_device"):
             return self(images)
         d = self.decoder
-        if self._lane_version != getattr(self.base_model, "_weights_version", 0):
-            self._lane(0)
-            self.base_model.set_option("use_graph", 0)      # lanes overlap only with direct launches
         x = _h.to_dev(images)
+        self.base_model._ensure(x.shape[0])            # the replicas inherit the base model's kernel table
         if self.lanes == 2 and not self._lanes_calibrated:
-            self.base_model._ensure(x.shape[0])        # the replicas inherit the tuned tile table
             self._lane(1)
             self._calibrate_lane_streams(x)
         i = (self._next_lane % self.lanes) if getattr(self, "_lanes_active", True) else 0

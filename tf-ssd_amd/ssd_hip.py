@@ -80,6 +80,9 @@ _SIGNATURES = {
     "ssd_net_finalize": (ctypes.c_int, [vp, ctypes.c_int]),
     "ssd_net_get_tuning": (ctypes.c_long, [vp, ctypes.c_char_p, ctypes.c_size_t]),
     "ssd_net_set_tuning": (ctypes.c_int, [vp, ctypes.c_char_p]),
+    "ssd_net_tuning_stats": (ctypes.c_int, [vp, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int)]),
+    "ssd_build_id": (ctypes.c_char_p, []),
+    "ssd_net_regularization_loss": (ctypes.c_int, [vp, c_float_p]),
     "ssd_net_num_priors": (ctypes.c_int, [vp]),
     "ssd_net_feature_map_size": (ctypes.c_int, [vp, ctypes.c_int]),
     "ssd_net_forward": (ctypes.c_int, [vp, vp, ctypes.c_int, vp, vp, vp]),
