@@ -191,7 +191,7 @@ class SSDModel(object):
         elif path and os.path.exists(path):
             with open(path) as f:
                 source, text = "cache", f.read()
-        elif not opts and tuning.load_shipped(key) is not None:
+        elif not opts and os.environ.get("SSD_HIP_IGNORE_SHIPPED", "0") != "1" and tuning.load_shipped(key) is not None:
             source, text = "shipped", tuning.load_shipped(key)
         elif tuning.memo_get(key, opts) is not None:
             source, text = "memo", tuning.memo_get(key, opts)
