@@ -13,7 +13,7 @@ m = get_model(hp, max_batch=B)
 data_utils.synthetic_weights(m)
 x = h.to_dev(data_utils.synthetic_images(B))
 m(x)
-names = ["prologue", "expand", "depthwise", "project", "wstage", "epilogue"]
+names = ["prologue", "barrier", "depthwise", "project", "expand", "epilogue"]   # row-band kernel (fuse_band 1); the 8x8-tile kernel: prologue, expand, depthwise, project, wstage, epilogue
 for k in (1, 2, 3, 4, 6):
     out = (ctypes.c_double * 6)()
     h.check(h.lib().ssd_net_profile_fused(m._net, ("block_%d_fused" % k).encode(), B, out), "profile_fused")

@@ -48,6 +48,7 @@ struct FusedBlockParams {
     int tiles_y, tiles_x;       // filled by the launcher
     // whole-image kernel (csrc/ssd_imgblock.hip): expanded-channel groups per image and their meeting point
     int groups;                 // G >= 1 (filled by the caller from image_block_groups)
+    int bands;                  // row-band kernel (csrc/ssd_bandblock.hip): bands per image (filled by the launcher)
     float* slabs;               // [G][B][Ho*Wo][Cout] partial sums (G > 1)
     unsigned* tickets;          // [B] arrival counters, zero between launches
     float* e_out;               // optional: the expanded map [B,H,W,Ce] is ALSO written to HBM (block 13: SSD feature map 1)
@@ -89,6 +90,8 @@ bool stem_supported(const StemParams& p);
 int launch_stem(StemParams p, hipStream_t st);
 bool fused_block_supported(const FusedBlockParams& p);
 int launch_fused_block(FusedBlockParams p, hipStream_t st);
+bool band_block_supported(const FusedBlockParams& p);
+int launch_band_block(FusedBlockParams p, hipStream_t st);
 bool image_block_supported(const FusedBlockParams& p);
 int image_block_groups(const FusedBlockParams& p, int B);
 size_t image_block_slab_floats(const FusedBlockParams& p, int B);

@@ -85,6 +85,7 @@ struct ssd_net {
     bool fuse_blocks = true;        // run eligible inverted-residual blocks as one fused kernel
     bool fuse_dwproj = true;        // ... and depthwise + project of the others as one kernel
     bool use_wino = true;           // offer the Winograd F(2x2,3x3) kernels to the autotune
+    bool fuse_band = true;          // row-band kernel (ssd_bandblock.hip) for blocks 1-6 instead of the 8x8-tile kernel
     int fuse_image = 1;             // whole-image block kernel (ssd_imgblock.hip): 0 never, 1 where it won the finalize-time race, 2 wherever it applies
     bool tail_on_side = false;      // diagnostics: big heads on the main stream, extras tail + small heads on the side streams
     bool image_ticket = false;      // combine the channel-group slabs inside the launch (arrival ticket) instead of by a second launch

@@ -433,7 +433,9 @@ static int run_layer_impl(ssd_net& net, const Layer& l, int B, float* deltas_out
             if (l.f_type == 2) return launch_dwproj(dwproj_params(net, l, B), st);
             {
                 const FusedBlockParams p = fused_params(net, l, B);
-                return fused_block_supported(p) ? launch_fused_block(p, st) : launch_image_block(p, st);
+                if (fused_block_supported(p))       // blocks 1-6: row-band kernel where it applies, else the 8x8-tile kernel
+                    return net.fuse_band && band_block_supported(p) ? launch_band_block(p, st) : launch_fused_block(p, st);
+                return launch_image_block(p, st);
             }
     }
     return SSD_OK;
@@ -1303,7 +1305,10 @@ int ssd_net_profile_fused(ssd_net* net, const char* layer, int B, double* cycles
     FusedBlockParams p = fused_params(*net, *f, B);
     const bool image = !fused_block_supported(p) && image_block_supported(p);
     SSD_CHECK_ARG(fused_block_supported(p) || image, "ssd_net_profile_fused: layer not supported by the fused kernels");
-    auto launch = [&](const FusedBlockParams& q) { return image ? launch_image_block(q, nullptr) : launch_fused_block(q, nullptr); };
+    const bool band = !image && net->fuse_band && band_block_supported(p);
+    auto launch = [&](const FusedBlockParams& q) {
+        return image ? launch_image_block(q, nullptr) : band ? launch_band_block(q, nullptr) : launch_fused_block(q, nullptr);
+    };
     if (const char* ab = getenv("SSD_FUSED_ABLATE")) {      // diagnostics: time the kernel with phases removed
         p.ablate = atoi(ab);
         hipEvent_t e0, e1;
@@ -1347,6 +1352,11 @@ int ssd_net_set_option(ssd_net* net, const char* name, int value) {
     SSD_CHECK_ARG(net && name, "ssd_net_set_option: NULL argument");
     if (std::string(name) == "fuse_blocks") {
         net->fuse_blocks = value != 0;
+        net->drop_graphs();
+        return SSD_OK;
+    }
+    if (std::string(name) == "fuse_band") {      // row-band kernel for blocks 1-6 (default 1; 0: the 8x8-tile kernel)
+        net->fuse_band = value != 0;
         net->drop_graphs();
         return SSD_OK;
     }
