@@ -39,8 +39,10 @@ def main():
     ap.add_argument("--img-size", type=int, default=300, help="300 (reference configs) or 512 (BASELINE configs[4] graph)")
     ap.add_argument("--cpu-sample", type=int, default=8, help="images per pass of the CPU baseline")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--lanes", type=int, default=2,
+    ap.add_argument("--lanes", type=int, default=1,
                     help="batches in flight per GPU (DecoderModel.submit): 2 = step n+1's backbone overlaps step n's heads / decode / NMS; 1 = strictly one step at a time")
+    ap.add_argument("--no-other-leg", action="store_true", help="skip the informational second mode (two lanes / one lane)")
+    ap.add_argument("--no-overlap", action="store_true", help="profiling runs: no intra-step side streams (option overlap_heads 0), so per-kernel durations are uncontended")
     ap.add_argument("--layers", action="store_true", help="also print the per-layer table to stderr")
     ap.add_argument("--train", action="store_true", help="time the training step (SURVEY 8f N1) instead of inference")
     args = ap.parse_args()
@@ -96,6 +98,8 @@ def main():
     if args.train:
         return train_bench(args, hp, get_model, rank, world, dist)
     model = get_model(hp, max_batch=B)
+    if args.no_overlap:
+        model.set_option("overlap_heads", 0)
     weights = data_utils.synthetic_weights(model, seed=1)
     priors = bbox_utils.generate_prior_boxes(hp["feature_map_shapes"], hp["aspect_ratios"])
     decoder_model = get_decoder_model(model, priors, hp, lanes=args.lanes)
@@ -105,30 +109,53 @@ def main():
         if dist is not None:
             dist.barrier()
 
-    # a step = one full pass (forward + decode/NMS) over one batch; with --lanes 2 consecutive steps run on
-    # two replicas of the net / two streams, so a step may start before the previous one has finished --
-    # every one of the K steps is complete at the synchronize that closes the timed region
-    for _ in range(max(args.warmup, 2 * args.lanes)):
-        out = decoder_model.submit(x)
-    decoder_model.wait()
-    torch.cuda.synchronize()
-    barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        out = decoder_model.submit(x)
-    decoder_model.wait()
-    torch.cuda.synchronize()
-    barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    # the same K steps strictly one at a time (lane 0 only): the per-step latency view
-    torch.cuda.synchronize()
-    t1 = time.perf_counter()
-    for _ in range(args.steps):
-        decoder_model(x)
-    torch.cuda.synchronize()
-    sequential_ms = (time.perf_counter() - t1) / args.steps * 1e3
+    # a step = one full pass (forward + decode/NMS) over one batch.  Default (--lanes 1): strictly one step at a
+    # time on the caller's stream -- the headline.  --lanes 2: consecutive steps run on two replicas of the net /
+    # two streams, so a step may start before the previous one has finished; every one of the K steps is complete
+    # at the synchronize that closes the timed region.
+    def run_steps(dm, n, lanes):
+        if lanes > 1:
+            for _ in range(n):
+                out = dm.submit(x, sync_input=False)        # x is resident and complete (contract: inputs in HBM)
+            dm.wait()
+        else:
+            for _ in range(n):
+                out = dm(x)
+        return out
+
+    def timed(dm, lanes):
+        run_steps(dm, max(args.warmup, 2 * lanes), lanes)
+        torch.cuda.synchronize()
+        barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        run_steps(dm, args.steps, lanes)
+        torch.cuda.synchronize()
+        barrier()
+        torch.cuda.synchronize()
+        return time.perf_counter() - t0
+
+    elapsed = timed(decoder_model, args.lanes)
+    # the other mode beside it (informational): two batches in flight when the headline is one step at a time,
+    # one step at a time when the headline keeps two in flight
+    other = None
+    if not args.no_other_leg:
+        if args.lanes == 1:
+            dm2 = get_decoder_model(model, priors, hp, lanes=2)
+            e2 = timed(dm2, 2)
+            other = {"mode": "two batches in flight (two net replicas on two streams, DecoderModel.submit)",
+                     "ms_per_step": 1e3 * e2 / args.steps, "images_per_sec": world * B * args.steps / e2,
+                     "lane_calibration": getattr(dm2, "lane_calibration", None)}
+            del dm2
+        else:
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(args.steps):
+                decoder_model(x)
+            torch.cuda.synchronize()
+            e1 = time.perf_counter() - t1
+            other = {"mode": "one step at a time", "ms_per_step": 1e3 * e1 / args.steps,
+                     "images_per_sec": world * B * args.steps / e1}
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -143,7 +170,7 @@ def main():
     info, nfw = model.read_timing(B)
     model.set_timing(False)
     # the dense-conv family on the fp32 matrix cores: implicit-GEMM tiles and Winograd F(2x2,3x3) tiles
-    mfma = [r for r in info if r["kind"] == "conv" and r["config"].startswith(("mfma_", "wino_")) and r["flops"] > 0]
+    mfma = [r for r in info if r["kind"] == "conv" and r["config"].startswith(("mfma_", "wino_", "skinny_")) and r["flops"] > 0]
     mfma_ms = sum(r["ms"] for r in mfma)
     mfma_flops = sum(r["flops"] for r in mfma)
     mfma_exec = sum(r["executed_flops"] for r in mfma)
@@ -156,10 +183,14 @@ def main():
         k = r["kind"]
         if k == "conv" and r["config"].startswith("wino_"):
             k = "conv_winograd"
-        elif k == "conv" and not r["config"].startswith("mfma_"):
+        elif k == "conv" and not r["config"].startswith(("mfma_", "skinny_")):
             k = "conv_direct"
         kinds[k] = kinds.get(k, 0.0) + r["ms"]
     achieved = mfma_flops / (mfma_ms * 1e-3) / 1e12 if mfma_ms > 0 else 0.0
+    executed = mfma_exec / (mfma_ms * 1e-3) / 1e12 if mfma_ms > 0 else 0.0
+    # the single most expensive launch of the family: what `rocprofv3 --kernel-trace --stats` of
+    # `bench.py --no-overlap --no-other-leg` lists as that kernel's average duration (profiles/)
+    dom = max(mfma, key=lambda r: r["ms"]) if mfma else None
     fused = [r for r in info if r["kind"] == "fused" and r["flops"] > 0]
     fused_ms = sum(r["ms"] for r in fused)
     fused_flops = sum(r["flops"] for r in fused)
@@ -209,9 +240,8 @@ def main():
         "steps": args.steps,
         "warmup": args.warmup,
         "ms_per_step": 1e3 * elapsed / args.steps,
-        # the same K steps strictly one at a time (no step starts before the previous one has finished)
-        "ms_per_step_sequential": sequential_ms,
-        "images_per_sec_sequential": world * B / (sequential_ms * 1e-3),
+        # informational: the same K steps in the OTHER launch mode (see --lanes)
+        "other_mode": other,
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,
@@ -223,26 +253,36 @@ def main():
                    "global_batch": world * B, "priors": model.num_priors, "labels": hp["total_labels"],
                    "mean_detections_per_image": mean_det, "nms_active": mean_det > 0, "parallelism": "batch-sharded x%d, no collective" % world,
                    "batches_in_flight_per_gpu": args.lanes,
-                   # which of the candidate stream pairs carries the two lanes was measured (DecoderModel)
-                   "lane_calibration": getattr(decoder_model, "lane_calibration", None)},
-        "roofline": {"bound": "mfma", "kernel": "conv_mfma_kernel + conv_wino_kernel (fp32 v_mfma_f32_16x16x4: implicit-GEMM and "
-                                                 "Winograd F(2x2,3x3) tiles, all configs)",
-                     # `achieved` counts ALGORITHMIC conv FLOPs (MACs x 2 of the direct
-                     # convolution); Winograd layers issue 2.25x fewer, so it may exceed `peak` --
-                     # `achieved_executed` / `frac_executed` count what the matrix cores really ran
-                     "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                     "frac": achieved / PEAK_FP32_MFMA_TFLOPS,
-                     "achieved_executed": mfma_exec / (mfma_ms * 1e-3) / 1e12 if mfma_ms > 0 else 0.0,
-                     "frac_executed": (mfma_exec / (mfma_ms * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS) if mfma_ms > 0 else 0.0,
+                   "lane_calibration": getattr(decoder_model, "lane_calibration", None),
+                   # where the kernel choices came from (tuning.py): a shipped table = nothing timed on the
+                   # device = the same kernels and bits in every process
+                   "kernel_table": getattr(model, "tuning_info", None)},
+        "roofline": {"bound": "mfma", "kernel": "conv_mfma_kernel + conv_wino_kernel + conv_skinny_kernel (fp32 v_mfma_f32_16x16x4: implicit-GEMM, "
+                                                 "Winograd F(2x2,3x3) and in-workgroup-split-K tiles, all configs)",
+                     # `achieved` / `frac` count the FLOPs the matrix cores actually ISSUED (Winograd layers: 16
+                     # multiplies per 2x2 output tile instead of 36, whole border tiles) over the hipEvent time of
+                     # the family's launches on their stream: a fraction of the peak, never above 1.  The
+                     # ALGORITHMIC figure (MACs x 2 of the direct convolution) is reported beside
+                     # it as `achieved_algorithmic`; for Winograd layers it is an "effective" rate and may exceed
+                     # the peak.
+                     "achieved": executed, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                     "frac": executed / PEAK_FP32_MFMA_TFLOPS, "frac_kind": "executed FLOPs / fp32 MFMA peak",
+                     "achieved_algorithmic": achieved, "frac_algorithmic": achieved / PEAK_FP32_MFMA_TFLOPS,
                      "winograd_layers": len(wino), "winograd_ms_per_step": sum(r["ms"] for r in wino),
                      "traffic": traffic, "traffic_detail": traffic_detail,
                      "launches_per_step": len(mfma), "kernel_ms_per_step": mfma_ms,
-                     "algorithmic_gflop_per_step": mfma_flops / 1e9,
-                     # the whole step (every kernel, incl. softmax/decode/NMS time) against the same peak
+                     "algorithmic_gflop_per_step": mfma_flops / 1e9, "executed_gflop_per_step": mfma_exec / 1e9,
+                     "dominant_kernel": None if dom is None else {
+                         "layer": dom["name"], "config": dom["config"], "ms_per_launch": dom["ms"],
+                         "algorithmic_gflop": dom["flops"] / 1e9, "executed_gflop": dom["executed_flops"] / 1e9,
+                         "achieved": dom["executed_flops"] / (dom["ms"] * 1e-3) / 1e12,
+                         "frac": dom["executed_flops"] / (dom["ms"] * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS,
+                         "achieved_algorithmic": dom["flops"] / (dom["ms"] * 1e-3) / 1e12},
+                     # the whole step (every kernel, incl. softmax/decode/NMS time) against the same peak, algorithmic FLOPs
                      "achieved_step": step_tflops, "frac_step": step_tflops / PEAK_FP32_MFMA_TFLOPS,
                      "algorithmic_gflop_per_step_all": step_flops / 1e9},
         # the other half of the step: whole-block / depthwise+project / stem kernels (MFMA + VALU depthwise)
-        "roofline_fused": {"bound": "mfma", "kernel": "mbv2_stem_kernel + mbv2_block_kernel + mbv2_image_block_kernel + dwproj8_kernel (fused inverted-residual family)",
+        "roofline_fused": {"bound": "mfma", "kernel": "mbv2_stem_kernel + mbv2_band_block_kernel + mbv2_image_block_kernel + dwproj8_kernel (fused inverted-residual family)",
                            "achieved": fused_flops / (fused_ms * 1e-3) / 1e12 if fused_ms > 0 else None,
                            "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
                            "frac": (fused_flops / (fused_ms * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS) if fused_ms > 0 else None,
@@ -324,6 +364,26 @@ def train_bench(args, hp, get_model, rank, world, dist):
                      "frac": step_tflops / PEAK_FP32_MFMA_TFLOPS, "traffic": None,
                      "algorithmic_gflop_per_step": 3.0 * fwd_gflop},
     }
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        # the oracle's training step (torch-CPU autograd graph of the identical network in training mode + loss;
+        # oracle/train_oracle.py) on the host cores: a bounded sample of the same workload
+        import numpy as np
+        from oracle import train_oracle as to
+        n = min(B, 4)
+        yd, yl = train_utils.calculate_actual_outputs(priors, gt[:n], gl[:n], hp)
+        w = model.get_weights()
+        xs, yds, yls = x[:n].cpu().numpy(), yd.cpu().numpy(), yl.cpu().numpy()
+        threads = min(16, os.cpu_count() or 1)
+        to.train_step(args.backbone, hp, w, xs, yds, yls, hp["neg_pos_ratio"], hp["loc_loss_alpha"], threads=threads)   # warm-up
+        t1 = time.perf_counter()
+        passes = 0
+        while passes < 4 and (passes == 0 or time.perf_counter() - t1 < 15.0):
+            to.train_step(args.backbone, hp, w, xs, yds, yls, hp["neg_pos_ratio"], hp["loc_loss_alpha"], threads=threads)
+            passes += 1
+        dt = time.perf_counter() - t1
+        result["cpu_baseline"] = {"value": n * passes / dt, "unit": "images/sec", "cores": threads, "host_cores": os.cpu_count(),
+                                  "kind": "port", "sample": "%d passes of the oracle's forward + loss + backward on %d images (torch-CPU "
+                                  "autograd, no optimiser step; TensorFlow itself is not installable here)" % (passes, n)}
     if rank == 0:
         print(json.dumps(result), flush=True)
     if dist is not None:

@@ -43,6 +43,14 @@ const char* ssd_last_error(void);
 /* Select + probe the device (must be gfx950).  Replaces utils/io_utils.py:54-61
  * (handle_gpu_compatibility) as the one-off per-process device hook. */
 int ssd_init(int device);
+/* A stream for keeping several batches in flight (DecoderModel lanes): created
+ * hipStreamNonBlocking, so work on it is NOT ordered against the legacy NULL stream -- an event recorded on the
+ * NULL stream (what torch's wait_stream does when the caller sits on the default stream) completes without
+ * waiting for the lanes, and two lanes really overlap.  (torch.cuda.Stream() objects are ordered against
+ * the NULL stream on this stack: recording the per-step dependency there serialised the lanes, measured.)
+ * high_priority != 0: the device's greatest stream priority.  Returns NULL on failure (ssd_last_error). */
+void* ssd_stream_create(int high_priority);
+int ssd_stream_destroy(void* stream);
 
 /* ---- prior boxes: utils/bbox_utils.py:115-176 (A1-A3) ------------------------------
  * fmaps[levels], n_ars[levels] and ars[levels][n_ars[l]] are HOST arrays; out_dev is

@@ -126,6 +126,14 @@ int wino_launch(const ConvParams& p, int i, hipStream_t st);
 size_t wino_weight_floats(int Cin, int Cout);
 int launch_wino_pack(const float* hwio, int Cin, int Cout, int Npad, int row_off, float* U, hipStream_t st);
 
+// Skinny path (csrc/ssd_skinny.hip): small-M / long-K convs with the K split inside the workgroup;
+// config ids [conv_num_mfma_configs() + wino_num_configs(), + skinny_num_configs())
+int skinny_num_configs();
+const char* skinny_config_name(int i);
+bool skinny_config_valid(int i, const ConvParams& p);
+long skinny_grid_blocks(int i, const ConvParams& p);
+int skinny_launch(const ConvParams& p, int i, hipStream_t st);
+
 int launch_dwconv3x3(const float* in, int B, int H, int W, int C, int stride, int pad_t, int pad_l,
                      int Ho, int Wo, const float* w, const float* scale, const float* shift, int act,
                      float* out, hipStream_t st);

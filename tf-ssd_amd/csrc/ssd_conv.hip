@@ -617,14 +617,18 @@ static const ConvCfg kCfgs[] = {
 constexpr int kNumMfmaCfgs = sizeof(kCfgs) / sizeof(kCfgs[0]);
 // config ids: [0, kNumMfmaCfgs) implicit-GEMM tiles, then the Winograd F(2x2,3x3) tiles
 // (csrc/ssd_wino.hip), last = VALU direct kernel
-static int direct_cfg() { return kNumMfmaCfgs + wino_num_configs(); }
+// then the skinny (in-workgroup K split) tiles (csrc/ssd_skinny.hip)
+static int skinny_cfg0() { return kNumMfmaCfgs + wino_num_configs(); }
+static int direct_cfg() { return kNumMfmaCfgs + wino_num_configs() + skinny_num_configs(); }
+#define kSkinnyCfg0 skinny_cfg0()
 #define kDirectCfg direct_cfg()
 
 int conv_num_mfma_configs() { return kNumMfmaCfgs; }
-int conv_num_configs() { return kNumMfmaCfgs + wino_num_configs() + 1; }
+int conv_num_configs() { return kNumMfmaCfgs + wino_num_configs() + skinny_num_configs() + 1; }
 const char* conv_config_name(int cfg) {
     if (cfg == kDirectCfg) return "direct_valu";
-    if (cfg >= kNumMfmaCfgs && cfg < kDirectCfg) return wino_config_name(cfg - kNumMfmaCfgs);
+    if (cfg >= kSkinnyCfg0 && cfg < kDirectCfg) return skinny_config_name(cfg - kSkinnyCfg0);
+    if (cfg >= kNumMfmaCfgs && cfg < kSkinnyCfg0) return wino_config_name(cfg - kNumMfmaCfgs);
     if (cfg < 0 || cfg >= kNumMfmaCfgs) return "?";
     return kCfgs[cfg].name;
 }
@@ -635,7 +639,8 @@ static bool is_gemm1x1(const ConvParams& p) {
 
 bool conv_config_valid(int cfg, const ConvParams& p) {
     if (cfg == kDirectCfg) return (size_t)p.K * ((p.Cout + 3) & ~3) * 4 <= 64 * 1024;
-    if (cfg >= kNumMfmaCfgs && cfg < kDirectCfg) return wino_config_valid(cfg - kNumMfmaCfgs, p);
+    if (cfg >= kSkinnyCfg0 && cfg < kDirectCfg) return skinny_config_valid(cfg - kSkinnyCfg0, p);
+    if (cfg >= kNumMfmaCfgs && cfg < kSkinnyCfg0) return wino_config_valid(cfg - kNumMfmaCfgs, p);
     if (cfg < 0 || cfg >= kNumMfmaCfgs) return false;
     if (((uintptr_t)p.in & 15) || ((uintptr_t)p.w & 15)) return false;
     if (p.Cin % 4) return false;
@@ -668,13 +673,15 @@ int conv_pick_config(const ConvParams& p) {
 }
 
 long conv_grid_blocks(int cfg, const ConvParams& p) {
-    if (cfg >= kNumMfmaCfgs && cfg < kDirectCfg) return wino_grid_blocks(cfg - kNumMfmaCfgs, p);
+    if (cfg >= kSkinnyCfg0 && cfg < kDirectCfg) return skinny_grid_blocks(cfg - kSkinnyCfg0, p);
+    if (cfg >= kNumMfmaCfgs && cfg < kSkinnyCfg0) return wino_grid_blocks(cfg - kNumMfmaCfgs, p);
     if (cfg < 0 || cfg >= kNumMfmaCfgs) return 0;
     const ConvCfg& g = kCfgs[cfg];
     return ((p.M + g.BM - 1) / g.BM) * ((p.Cout + g.BN - 1) / g.BN);
 }
 int conv_k_tiles(int cfg, const ConvParams& p) {
-    if (cfg >= kNumMfmaCfgs && cfg < kDirectCfg) return wino_k_tiles(p);
+    if (cfg >= kSkinnyCfg0 && cfg < kDirectCfg) return p.K / 16;
+    if (cfg >= kNumMfmaCfgs && cfg < kSkinnyCfg0) return wino_k_tiles(p);
     if (cfg < 0 || cfg >= kNumMfmaCfgs) return 0;
     return (p.K + kCfgs[cfg].BK - 1) / kCfgs[cfg].BK;
 }
@@ -690,7 +697,8 @@ int conv_launch(const ConvParams& p, int cfg, hipStream_t st) {
                   p.Cin, p.kh, p.kw, p.stride);
         return SSD_E_UNSUPPORTED;
     }
-    if (cfg >= kNumMfmaCfgs && cfg < kDirectCfg) {
+    if (cfg >= kSkinnyCfg0 && cfg < kDirectCfg) return skinny_launch(p, cfg - kSkinnyCfg0, st);
+    if (cfg >= kNumMfmaCfgs && cfg < kSkinnyCfg0) {
         const int rc = wino_launch(p, cfg - kNumMfmaCfgs, st);
         if (rc || p.split_k <= 1) return rc;
         return launch_splitk_reduce(p, st);

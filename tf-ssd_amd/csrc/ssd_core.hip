@@ -21,6 +21,23 @@ const char* ssd_build_id(void) { return SSD_BUILD_ID; }
 
 const char* ssd_last_error(void) { return ssd::g_err; }
 
+void* ssd_stream_create(int high_priority) {
+    hipStream_t s = nullptr;
+    int lo = 0, hi = 0;     // (least, greatest): numerically lower = higher priority
+    (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+    const hipError_t e = hipStreamCreateWithPriority(&s, hipStreamNonBlocking, high_priority ? hi : 0);      // 0 = the default priority
+    if (e != hipSuccess) {
+        ssd::set_error("ssd_stream_create: %s", hipGetErrorString(e));
+        (void)hipGetLastError();
+        return nullptr;
+    }
+    return (void*)s;
+}
+int ssd_stream_destroy(void* stream) {
+    if (stream) SSD_HIP(hipStreamDestroy((hipStream_t)stream));
+    return SSD_OK;
+}
+
 int ssd_init(int device) {
     int n = 0;
     SSD_HIP(hipGetDeviceCount(&n));

@@ -87,6 +87,7 @@ struct ssd_net {
     bool use_wino = true;           // offer the Winograd F(2x2,3x3) kernels to the autotune
     bool fuse_band = true;          // row-band kernel (ssd_bandblock.hip) for blocks 1-6 instead of the 8x8-tile kernel
     int fuse_image = 1;             // whole-image block kernel (ssd_imgblock.hip): 0 never, 1 where it won the finalize-time race, 2 wherever it applies
+    int tail_prio = 0;              // 1: extras tail on side[2] (highest priority); 2: its small heads too
     bool tail_on_side = false;      // diagnostics: big heads on the main stream, extras tail + small heads on the side streams
     bool image_ticket = false;      // combine the channel-group slabs inside the launch (arrival ticket) instead of by a second launch
     float* img_slabs = nullptr;     // its partial-sum slabs and arrival tickets (sized for max_batch)
@@ -126,9 +127,9 @@ struct ssd_net {
     // the head convs only depend on their feature map: they run on `side` concurrently with the
     // rest of the backbone / extras (fork after the producer, join before the softmax)
     bool overlap_heads = true;
-    static constexpr int kSides = 2;
-    hipStream_t side[kSides] = {nullptr, nullptr};
-    hipEvent_t ev_side_done[kSides] = {nullptr, nullptr};
+    static constexpr int kSides = 3;       // [2]: highest-priority stream for the latency-bound extras tail (option tail_prio)
+    hipStream_t side[kSides] = {nullptr, nullptr, nullptr};
+    hipEvent_t ev_side_done[kSides] = {nullptr, nullptr, nullptr};
     float* splitk_layers = nullptr;     // per-layer split-K slabs (post-autotune)
     bool timing = false;
     ssd_train_state* train = nullptr;    // training step state (csrc/ssd_train.hip), lazily created

@@ -687,6 +687,7 @@ ssd_net* ssd_net_create(int backbone, int img_size, int levels, const int* n_ars
         }
     if (backbone == SSD_MOBILENET_V2) build_mobilenet_v2(*net);
     else build_vgg16(*net);
+    if (const char* g = getenv("SSD_TAIL_PRIO")) net->tail_prio = atoi(g) < 0 ? 0 : (atoi(g) > 2 ? 2 : atoi(g));    // diagnostics
     if (const char* g = getenv("SSD_HIP_USE_GRAPH")) {      // diagnostics: pin the launch mode (0 direct, 1 graph replay)
         net->use_graph = atoi(g) != 0;
         net->use_graph_auto = false;
@@ -994,7 +995,15 @@ int ssd_net_finalize(ssd_net* net, int max_batch) {
                 }
         }
         for (int k = 0; k < ssd_net::kSides; ++k) {
-            if (!net->side[k]) SSD_HIP(hipStreamCreateWithFlags(&net->side[k], hipStreamNonBlocking));
+            if (!net->side[k]) {
+                if (k == 2) {       // the tail's stream: highest priority the device offers
+                    int lo = 0, hi = 0;
+                    (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+                    SSD_HIP(hipStreamCreateWithPriority(&net->side[k], hipStreamNonBlocking, hi));
+                } else {
+                    SSD_HIP(hipStreamCreateWithFlags(&net->side[k], hipStreamNonBlocking));
+                }
+            }
             if (!net->ev_side_done[k]) SSD_HIP(hipEventCreateWithFlags(&net->ev_side_done[k], hipEventDisableTiming));
         }
         for (auto& l : net->layers)
@@ -1146,10 +1155,15 @@ static int forward_impl(ssd_net* net, const float* image_dev, int B, float* delt
         for (int i = 0; i < nl; ++i) {      // tail chain (+ its small heads right behind their producers)
             const Layer& l = net->layers[i];
             if (placed[i] || l.side || l.kind == LK_SOFTMAX) continue;
-            sid[i] = tail_on_side ? 0 : -1;
+            sid[i] = tail_on_side ? 0 : (net->tail_prio ? 2 : -1);
             order.push_back(i);
             placed[i] = 1;
-            if (l.out > 0 && layer_runs(*net, l)) place_small_heads(l.out);
+            if (l.out > 0 && layer_runs(*net, l)) {
+                const size_t o0 = order.size();
+                place_small_heads(l.out);
+                if (net->tail_prio == 2)
+                    for (size_t oo = o0; oo < order.size(); ++oo) sid[order[oo]] = 2;
+            }
         }
         for (int i = 0; i < nl; ++i)        // anything left (small heads without a running producer), then softmax
             if (!placed[i] && net->layers[i].kind != LK_SOFTMAX) { sid[i] = net->layers[i].side == 2 ? 1 : -1; order.push_back(i); placed[i] = 1; }
@@ -1176,7 +1190,7 @@ static int forward_impl(ssd_net* net, const float* image_dev, int B, float* delt
                 if (pr >= 0 && sid[pr] != sid[i]) publishes[pr] = 1;
             }
         }
-    bool side_used[ssd_net::kSides] = {false, false};
+    bool side_used[ssd_net::kSides] = {false, false, false};
     auto join_sides = [&]() -> int {
         for (int k = 0; k < ssd_net::kSides; ++k)
             if (side_used[k]) {
@@ -1365,6 +1379,11 @@ int ssd_net_set_option(ssd_net* net, const char* name, int value) {
         net->drop_graphs();
         return SSD_OK;
     }
+    if (std::string(name) == "tail_prio") {      // extras tail (2: + its small heads) on a highest-priority stream
+        net->tail_prio = value < 0 ? 0 : (value > 2 ? 2 : value);
+        net->drop_graphs();
+        return SSD_OK;
+    }
     if (std::string(name) == "tail_on_side") {
         net->tail_on_side = value != 0;
         net->drop_graphs();
@@ -1489,7 +1508,7 @@ double ssd_net_layer_executed_flops(const ssd_net* net, int i, int B) {
     if (!net || i < 0 || i >= (int)net->layers.size()) return 0;
     const Layer& l = net->layers[i];
     if (!layer_runs(*net, l)) return 0;
-    if (l.kind == LK_CONV && l.cfg >= conv_num_mfma_configs() && l.cfg < conv_num_configs() - 1)
+    if (l.kind == LK_CONV && l.cfg >= conv_num_mfma_configs() && l.cfg < conv_num_mfma_configs() + wino_num_configs())
         return 2.0 * B * ((l.Ho + 1) / 2) * ((l.Wo + 1) / 2) * 16.0 * l.Cin * l.Cout;
     return ssd_net_layer_flops(net, i, B);
 }

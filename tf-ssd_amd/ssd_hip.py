@@ -82,6 +82,8 @@ _SIGNATURES = {
     "ssd_net_set_tuning": (ctypes.c_int, [vp, ctypes.c_char_p]),
     "ssd_net_tuning_stats": (ctypes.c_int, [vp, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int)]),
     "ssd_build_id": (ctypes.c_char_p, []),
+    "ssd_stream_create": (vp, [ctypes.c_int]),
+    "ssd_stream_destroy": (ctypes.c_int, [vp]),
     "ssd_net_regularization_loss": (ctypes.c_int, [vp, c_float_p]),
     "ssd_net_num_priors": (ctypes.c_int, [vp]),
     "ssd_net_feature_map_size": (ctypes.c_int, [vp, ctypes.c_int]),
@@ -161,6 +163,16 @@ def device():
 
 def stream():
     return vp(torch.cuda.current_stream().cuda_stream)
+
+
+def new_stream(high_priority=False):
+    """A non-blocking native stream (``ssd_stream_create``) as a torch stream object: not ordered against
+    the legacy NULL stream, unlike ``torch.cuda.Stream()`` on this stack (DecoderModel lanes)."""
+    device()
+    h = lib().ssd_stream_create(1 if high_priority else 0)
+    if not h:
+        raise SsdHipError("ssd_stream_create: %s" % lib().ssd_last_error().decode())
+    return torch.cuda.ExternalStream(h)
 
 
 def to_dev(x, dtype=torch.float32):
