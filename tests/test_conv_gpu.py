@@ -340,6 +340,75 @@ def test_entry_point_scripts(tmp_path, monkeypatch, capsys):
     assert "predicted 40 images" in out
 
 
+def test_predictor_custom_images_and_evaluate(tmp_path, monkeypatch, capsys):
+    """E1 wired to N4 and N2 (reference predictor.py:10-12, 35-40, 54-55): ``use_custom_images`` reads uint8
+    images from ``custom_image_path`` (PIL + LANCZOS on the host like the reference, uint8 -> float on the
+    GPU) and must give the detections of the same model on the identically prepared arrays; ``evaluate``
+    drops difficult objects in ``preprocessing`` and returns the VOC07 mAP statistics, equal to the
+    oracle's on the same predictions / ground truth."""
+    import importlib
+    from PIL import Image
+    from models.decoder import get_decoder_model
+    from models.ssd_mobilenet_v2 import get_model
+    from oracle import eval_oracle as eo
+    from utils import bbox_utils, data_utils, train_utils
+    monkeypatch.chdir(tmp_path)
+    predictor = importlib.import_module("predictor")
+    rng = np.random.default_rng(77)
+    d = tmp_path / "imgs"
+    d.mkdir()
+    arrays = []
+    for i, (h, w) in enumerate([(375, 500), (333, 500), (300, 300), (480, 360), (512, 512)]):
+        a = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+        if i % 2:
+            Image.fromarray(a).save(str(d / ("img_%d.png" % i)))
+        else:
+            np.save(str(d / ("img_%d.npy" % i)), a)
+        arrays.append((("img_%d.png" if i % 2 else "img_%d.npy") % i, a))
+    b, l, s = predictor.main(["--backbone", "mobilenet_v2"], use_custom_images=True, custom_image_path=str(d), batch_size=4)
+    assert b.shape == (5, 200, 4) and "predicted 5 images" in capsys.readouterr().out
+    # the same model on the arrays prepared on the host: LANCZOS resize, then / 255 in float32
+    hp = train_utils.get_hyper_params("mobilenet_v2")
+    hp["total_labels"] = 21
+    m = get_model(hp, max_batch=4)
+    data_utils.synthetic_weights(m)
+    pri = bbox_utils.generate_prior_boxes(hp["feature_map_shapes"], hp["aspect_ratios"])
+    dm = get_decoder_model(m, pri, hp)
+    host = np.stack([np.asarray(Image.fromarray(a).resize((300, 300), Image.LANCZOS), np.uint8)
+                     for _, a in sorted(arrays)]).astype(np.float32) * np.float32(1.0 / 255.0)
+    rb, rl, rs = dm.predict(host, batch_size=4)
+    np.testing.assert_array_equal(l, rl)
+    np.testing.assert_array_equal(s, rs)
+    np.testing.assert_array_equal(b, rb)
+    assert ((l > 0).sum(-1) > 0).all()
+    # evaluate=True: difficult objects filtered in preprocessing, mAP bookkeeping = the oracle's
+    monkeypatch.setenv("SSD_SYNTHETIC_ITEMS", "12")
+    b, l, s, stats = predictor.main(["--backbone", "mobilenet_v2"], evaluate=True, batch_size=5)
+    out = capsys.readouterr().out
+    assert "mAP: " in out and b.shape[0] == 12
+    items = list(data_utils.synthetic_voc_items(12, 21))
+    kept = sum(int((~it["objects"]["is_difficult"]).sum()) for it in items)
+    assert sum(rec["total"] for rec in stats.values()) == kept < sum(len(it["objects"]["label"]) for it in items)
+    labels = ["bg"] + data_utils.get_labels()
+    ref = eo.init_stats(labels)
+    gts = [(it["objects"]["bbox"][~it["objects"]["is_difficult"]], (it["objects"]["label"][~it["objects"]["is_difficult"]] + 1).astype(np.int32))
+           for it in items]
+    for i in range(0, 12, 5):
+        chunk = gts[i:i + 5]
+        g = max([len(c[0]) for c in chunk] + [1])
+        gt = np.zeros((len(chunk), g, 4), np.float32)
+        gl = -np.ones((len(chunk), g), np.int32)
+        for j, (bb, ll) in enumerate(chunk):
+            gt[j, :len(bb)] = bb
+            gl[j, :len(ll)] = ll
+        eo.update_stats(b[i:i + 5], l[i:i + 5], s[i:i + 5], gt, gl, ref)
+    ref, ref_map = eo.calculate_mAP(ref)
+    for cid in ref:
+        assert ref[cid]["total"] == stats[cid]["total"] and ref[cid]["tp"] == stats[cid]["tp"], cid
+        np.testing.assert_array_equal(np.asarray(ref[cid]["AP"]), np.asarray(stats[cid]["AP"]))
+    assert ("mAP: %s" % float(ref_map)) in out
+
+
 def test_eval_utils_map():
     """VOC07 11-point mAP (N2): perfect predictions -> AP 1; shuffled labels -> lower."""
     from utils import eval_utils

@@ -293,3 +293,33 @@ def test_new_entry_points_validate_without_a_device():
     assert l.ssd_net_train_begin(net, 4) == -4 and b"never set" in l.ssd_last_error()
     assert l.ssd_net_train_steps(net) == 0 and l.ssd_net_train_fetch(net, b"probs", 1, None, 0) < 0
     l.ssd_net_destroy(net)
+
+
+def test_data_utils_padded_batch_and_custom_image_listing(tmp_path):
+    """Host logic of the reference's dataset plumbing (utils/data_utils.py:47-59, 80-91, 117-122; predictor.py:43):
+    padded batches (ground truth padded with 0 / -1 to the longest of the batch, ragged last batch), the listing
+    of custom images (files directly inside the directory, no recursion), the item-size helper."""
+    import numpy as np
+    from utils import data_utils
+    items = []
+    rng = np.random.default_rng(0)
+    for g in (3, 0, 5, 1, 2):
+        items.append((rng.random((8, 8, 3), dtype=np.float32), rng.random((g, 4), dtype=np.float32),
+                      rng.integers(1, 21, g).astype(np.int32)))
+    batches = list(data_utils.padded_batch(iter(items), 2))
+    assert [b[0].shape[0] for b in batches] == [2, 2, 1]
+    assert batches[0][1].shape == (2, 3, 4) and batches[1][1].shape == (2, 5, 4) and batches[2][1].shape == (1, 2, 4)
+    np.testing.assert_array_equal(batches[0][2][1], [-1, -1, -1])          # the empty item: all padding
+    np.testing.assert_array_equal(batches[0][1][1], np.zeros((3, 4), np.float32))
+    np.testing.assert_array_equal(batches[1][2][1], [items[3][2][0], -1, -1, -1, -1])
+    np.testing.assert_array_equal(batches[1][1][0], items[2][1])
+    np.testing.assert_array_equal(batches[1][0][1], items[3][0])
+    (tmp_path / "sub").mkdir()
+    for n in ("b.png", "a.jpg", "sub/c.png"):
+        (tmp_path / n).write_bytes(b"x")
+    assert data_utils.get_custom_imgs(str(tmp_path)) == [str(tmp_path / "a.jpg"), str(tmp_path / "b.png")]
+    assert data_utils.get_total_item_size({"splits": {"train": 5, "validation": 7, "test": 9}}, "train+validation") == 12
+    assert data_utils.get_total_item_size({"splits": {"train": 5, "validation": 7, "test": 9}}, "test") == 9
+    its = list(data_utils.synthetic_voc_items(3, 21, seed=1))
+    assert all(it["image"].dtype == np.uint8 and it["image"].ndim == 3 for it in its)
+    assert all(it["objects"]["label"].max() <= 19 and len(it["objects"]["bbox"]) == len(it["objects"]["is_difficult"]) for it in its)

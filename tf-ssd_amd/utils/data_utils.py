@@ -65,6 +65,89 @@ def get_dataset(name, split, data_dir="~/tensorflow_datasets"):
                        "[B,S,S,3] float32 in [0,1] directly")
 
 
+def get_total_item_size(info, split):
+    """reference utils/data_utils.py:47-59 (``info`` here: a dict ``{"splits": {name: count}}`` or an int)."""
+    assert split in ["train", "train+validation", "validation", "test"]
+    if isinstance(info, int):
+        return info
+    if split == "train+validation":
+        return info["splits"]["train"] + info["splits"]["validation"]
+    return info["splits"][split]
+
+
+def get_custom_imgs(custom_image_path):
+    """reference utils/data_utils.py:80-91: the files directly inside ``custom_image_path`` (no recursion)."""
+    import os
+    img_paths = []
+    for path, _dirs, filenames in os.walk(custom_image_path):
+        for filename in sorted(filenames):
+            img_paths.append(os.path.join(path, filename))
+        break
+    return img_paths
+
+
+def custom_data_generator(img_paths, final_height, final_width):
+    """reference utils/data_utils.py:93-108: every image opened with PIL and resized with LANCZOS on the host
+    (the reference's choice for custom images -- dataset images take the bilinear ``preprocessing`` path),
+    then uint8 -> float32 [0,1] (``tf.image.convert_image_dtype``) on the GPU (``ssd_preprocess`` at equal
+    sizes is exactly that conversion).  ``*.npy`` files (uint8 [H,W,3]) are accepted as well.  Yields
+    ``(img [final_height, final_width, 3] device tensor, gt_boxes [0,4], gt_labels [0])``."""
+    from PIL import Image
+    for img_path in img_paths:
+        if img_path.endswith(".npy"):
+            image = Image.fromarray(np.load(img_path))
+        else:
+            image = Image.open(img_path).convert("RGB")
+        resized = np.ascontiguousarray(np.array(image.resize((final_width, final_height), Image.LANCZOS), dtype=np.uint8))
+        img = preprocess_batch(resized[None], final_height, final_width)[0]
+        yield img, np.zeros((0, 4), np.float32), np.zeros((0,), np.int32)
+
+
+def padded_batch(items, batch_size, padding_values=None):
+    """``Dataset.padded_batch(batch_size, padded_shapes=data_shapes, padding_values=...)`` of the reference
+    scripts (predictor.py:43, trainer.py:33-34): consecutive ``(img, gt_boxes, gt_labels)`` items are stacked,
+    ground truth padded to the longest of the batch with 0 / -1.  Images stay where they are (device tensors
+    are stacked on the device)."""
+    import torch
+    pv = padding_values or get_padding_values()
+    batch = []
+
+    def flush():
+        g = max([len(b[1]) for b in batch] + [1])
+        gt = np.full((len(batch), g, 4), pv[1], np.float32)
+        gl = np.full((len(batch), g), pv[2], np.int32)
+        for i, (_, bb, ll) in enumerate(batch):
+            gt[i, :len(bb)] = np.asarray(bb, np.float32).reshape(-1, 4)
+            gl[i, :len(ll)] = np.asarray(ll, np.int32)
+        imgs = [b[0] for b in batch]
+        x = torch.stack(imgs) if isinstance(imgs[0], torch.Tensor) else np.stack(imgs)
+        return x, gt, gl
+
+    for it in items:
+        batch.append(it)
+        if len(batch) == batch_size:
+            yield flush()
+            batch = []
+    if batch:
+        yield flush()
+
+
+def synthetic_voc_items(total_items, total_labels=21, seed=0):
+    """Seeded stand-in for ``tfds.load("voc/2007")`` items: dicts ``{"image": uint8 [H,W,3] (VOC-like sizes, H / W
+    in 300..500), "objects": {"bbox" [G,4] normalised, "label" [G] in 0..total_labels-2 (``preprocessing`` adds
+    1), "is_difficult" [G]}}`` -- what ``preprocessing`` consumes (utils/data_utils.py:7-30)."""
+    rng = np.random.default_rng(seed)
+    for _ in range(total_items):
+        h, w = int(rng.integers(300, 501)), int(rng.integers(300, 501))
+        g = int(rng.integers(1, 9))
+        c = rng.uniform(0.15, 0.85, (g, 2))
+        sz = rng.uniform(0.08, 0.5, (g, 2))
+        yield {"image": rng.integers(0, 256, (h, w, 3), dtype=np.uint8),
+               "objects": {"bbox": np.clip(np.concatenate([c - sz / 2, c + sz / 2], -1), 0, 1).astype(np.float32),
+                           "label": rng.integers(0, total_labels - 1, g).astype(np.int64),
+                           "is_difficult": rng.random(g) < 0.2}}
+
+
 def get_padding_values():
     """reference utils/data_utils.py:117-122: image 0, gt boxes 0, gt labels -1."""
     return (np.float32(0), np.float32(0), np.int32(-1))
