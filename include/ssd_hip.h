@@ -335,6 +335,13 @@ int ssd_net_train_forward_backward(ssd_net* net, const float* image_dev, int B,
                                    const float* actual_deltas_dev, const float* actual_labels_dev,
                                    float neg_pos_ratio, float loc_loss_alpha, float* grads_flat_dev,
                                    float* loc_loss_dev, float* conf_loss_dev, void* stream);
+/* Gradient buckets for the batch data-parallel step (the reference trains on one device, trainer.py:50-76; the
+ * RCCL exchange is this build's SURVEY.md 8e row 2): bucket k = flat offsets [lo[k], lo[k + 1]), lo ascending
+ * from 0.  The backward finishes the flat gradient vector from its end (heads first, stem last) and records an
+ * event per bucket when it is final; ssd_net_train_wait_bucket(net, k, stream) orders `stream` -- the one the
+ * all-reduce of bucket k is issued on -- behind that point, so the exchange overlaps the rest of the backward. */
+int ssd_net_train_set_buckets(ssd_net* net, int n, const long* lo);
+int ssd_net_train_wait_bucket(ssd_net* net, int k, void* stream);
 /* Adam (Keras defaults beta1 0.9, beta2 0.999, eps 1e-7; TF ApplyAdam form) on every trainable
  * parameter; grads are multiplied by grad_scale first (1/world_size after a SUM all-reduce). */
 int ssd_net_adam_step(ssd_net* net, const float* grads_flat_dev, float lr, float beta1, float beta2,

@@ -3,6 +3,7 @@
 (oracle/train_oracle.py).  Bars: network outputs 1e-4 abs; per-image losses 1e-4 rel; every
 parameter gradient within 1e-3 of the tensor's max |gradient| (fp32, ~50 layers, batch statistics);
 BatchNorm moving averages 1e-5; Adam update vs the NumPy ApplyAdam on the same gradients 1e-6."""
+import ctypes
 import os
 import subprocess
 import sys
@@ -55,6 +56,43 @@ for t in gathered:
 dist.destroy_process_group()
 print("DP_OK", rank)
 '''
+
+
+_DP_READY_WORKER = r'''
+import os, sys
+import numpy as np, torch, torch.distributed as dist
+sys.path[:0] = [sys.argv[1], os.path.join(sys.argv[1], "tf-ssd_amd")]
+import parallel
+rank, _, world = parallel.init_distributed("gloo")
+n = 1003
+g = torch.from_numpy(np.random.default_rng(100 + rank).standard_normal(n).astype(np.float32))
+ref = sum(np.random.default_rng(100 + r).standard_normal(n).astype(np.float32) for r in range(world))
+starts = parallel.bucket_starts(n, 4)
+assert starts[0] == 0 and all(s % 4 == 0 for s in starts) and len(starts) == 4 and starts == sorted(set(starts))
+order = []
+w = parallel.allreduce_gradients_as_ready(g, starts, wait_bucket=lambda k, st: order.append(k), comm_stream=None)
+assert w == world and order == [3, 2, 1, 0], order          # issued in the order the backward finishes them: from the END
+np.testing.assert_allclose(g.numpy(), ref, rtol=1e-6, atol=1e-6)
+dist.destroy_process_group()
+print("DP_OK", rank)
+'''
+
+
+def test_two_process_gloo_gradient_buckets_as_ready(tmp_path):
+    """World-size-2 gloo run of the bucket-as-ready exchange: buckets go out last-to-first (the order the native
+    backward completes them), every bucket behind its completion hook, the sum is exact."""
+    script = tmp_path / "w.py"
+    script.write_text(_DP_READY_WORKER)
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE="2")
+    procs = [subprocess.Popen([sys.executable, str(script), REPO], env=dict(env, RANK=str(r), LOCAL_RANK=str(r)),
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(2)]
+    outs = [p.communicate(timeout=300)[0] for p in procs]
+    for r, (p, o) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0 and "DP_OK %d" % r in o, o[-2000:]
 
 
 @pytest.mark.parametrize("bucket", [0, 300])
@@ -259,6 +297,50 @@ def test_train_step_c4_per_gpu_shape():
         m.apply_gradients(m._grads, learning_rate=LR)
         l2, c2, _ = m.forward_backward(x, yd, yl)
     assert float((l2 + c2).mean()) < first
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("backbone", ["mobilenet_v2", "vgg16"])
+def test_gradient_bucket_events(backbone):
+    """Bucket-as-ready exchange, device side (``ssd_net_train_set_buckets`` / ``ssd_net_train_wait_bucket``): a
+    second stream that waits for bucket k's completion event and copies the bucket out right away must see the
+    FINAL gradients of that bucket -- the flat vector starts NaN-filled, so an event recorded before the last
+    kernel that writes into the bucket (weight gradients, BatchNorm / bias reductions, VGG16's l2 term) would
+    leak NaN or partial sums into the snapshot -- and the result equals the un-bucketed step bit for bit."""
+    import torch
+    import ssd_hip as h
+    if backbone == "mobilenet_v2":
+        from models.ssd_mobilenet_v2 import get_model
+    else:
+        from models.ssd_vgg16 import get_model
+    hp = helpers.hyper_params(backbone)
+    w = helpers.synthetic_weights(backbone, hp)
+    B = 2
+    x = helpers.images(B, 300, seed=31)
+    yd, yl = _targets(hp, B, seed=6)
+    m = get_model(hp)
+    m.set_weights(w)
+    m.compile()
+    _, _, g0 = m.forward_backward(x, yd, yl)
+    g0 = g0.cpu().numpy().copy()
+    starts = m._plan_gradient_buckets(B, 5)
+    assert starts[0] == 0 and len(starts) == 5
+    side = h.new_stream()
+    m._grads.fill_(float("nan"))
+    snap = torch.full_like(m._grads, float("nan"))
+    torch.cuda.synchronize()
+    loc, conf, g = m.forward_backward(x, yd, yl)
+    bounds = list(starts) + [g.numel()]
+    for k in reversed(range(len(starts))):
+        h.check(h.lib().ssd_net_train_wait_bucket(m._net, k, h.vp(side.cuda_stream)), "wait_bucket")
+        with torch.cuda.stream(side):
+            snap[bounds[k]:bounds[k + 1]].copy_(g[bounds[k]:bounds[k + 1]], non_blocking=True)
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(g.cpu().numpy(), g0)                 # the bucket plan does not change the arithmetic
+    np.testing.assert_array_equal(snap.cpu().numpy(), g0)              # every bucket was final at its event
+    with pytest.raises(ValueError):
+        arr = (ctypes.c_long * 2)(0, 0)
+        h.check(h.lib().ssd_net_train_set_buckets(m._net, 2, arr), "set_buckets")
 
 
 @pytest.mark.gpu

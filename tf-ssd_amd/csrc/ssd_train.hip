@@ -866,10 +866,18 @@ struct ssd_train_state {
     void* loss_ws = nullptr;
     size_t loss_ws_bytes = 0;
     long step = 0;
+    // gradient buckets for the data-parallel exchange (ssd_net_train_set_buckets): bucket k = flat offsets
+    // [bucket_lo[k], bucket_lo[k + 1]) and is FINAL once the backward has passed every layer that owns a
+    // parameter at or above bucket_lo[k]; bucket_ev[k] is recorded on the backward's stream right there
+    std::vector<long> bucket_lo;
+    std::vector<hipEvent_t> bucket_ev;
+    std::vector<long> pending_hi;       // per layer i: end of the highest parameter of any ACTIVE layer j < i (0: none)
 };
 
 void ssd_train_state_free(ssd_train_state* s) {
     if (!s) return;
+    for (auto e : s->bucket_ev)
+        if (e) (void)hipEventDestroy(e);
     for (float* p : s->owned)
         if (p) (void)hipFree(p);
     if (s->loss_ws) (void)hipFree(s->loss_ws);
@@ -1343,10 +1351,24 @@ int ssd_net_train_forward_backward(ssd_net* net, const float* image_dev, int B, 
 
     // ------------------------------------------------------------ backward
     std::fill(s.gwritten.begin(), s.gwritten.end(), 0);
+    // gradient buckets: everything at or above `threshold` in the flat vector is final -> publish those buckets
+    size_t next_bucket = s.bucket_lo.size();
+    auto mark_ready = [&](long threshold) -> int {
+        while (next_bucket > 0 && s.bucket_lo[next_bucket - 1] >= threshold) {
+            if (getenv("SSD_HIP_DEBUG_BUCKETS")) fprintf(stderr, "[ssd] bucket %zu (lo %ld) final at threshold %ld\n", next_bucket - 1, s.bucket_lo[next_bucket - 1], threshold);
+            SSD_HIP(hipEventRecord(s.bucket_ev[next_bucket - 1], st));
+            --next_bucket;
+        }
+        return SSD_OK;
+    };
     for (int i = (int)net->layers.size() - 1; i >= 0; --i) {
         const Layer& l = net->layers[i];
         TrainLayer& t = s.tl[i];
         if (!t.active) continue;
+        if (!s.pending_hi.empty()) {        // layers > i are done: what no layer <= i owns is final
+            rc = mark_ready(s.pending_hi[i]);
+            if (rc) return rc;
+        }
         const long M = (long)B * l.Ho * l.Wo;
         const float* x = s.act[l.in];
         if (l.kind == LK_POOL || l.kind == LK_L2NORM) {
@@ -1479,6 +1501,15 @@ int ssd_net_train_forward_backward(ssd_net* net, const float* image_dev, int B, 
             if (!rc) rc = wgrad(s, l, B, x, dY + l.Cout1, ldy, l.Cout - l.Cout1, grads_flat_dev + t.g_kernel2, st);
         }
         if (rc) return rc;
+        // VGG16: kernel_regularizer=l2(5e-4) on every backbone / extra conv (models/ssd_vgg16.py:44-45; the head
+        // convs of models/header.py have none): d(5e-4 * sum w^2)/dw = 1e-3 * w, added right behind the layer's
+        // weight gradient so that the gradient bucket it lies in is final when the backward has passed the layer
+        if (net->backbone == SSD_VGG16 && !l.head_kind) {
+            const Param& w = net->params[l.p_kernel];
+            hipLaunchKernelGGL(axpy_kernel, dim3(grid_for((long)w.count)), dim3(256), 0, st, grads_flat_dev + t.g_kernel,
+                               w.dev, (long)w.count, 2.0f * 5e-4f);
+            SSD_LAUNCH_CHECK();
+        }
         // ---- data gradient: conv of dY with the rotated / transposed weights
         if (!t.wbwd) continue;
         const int d = l.dil, kh = l.kh, kw = l.kw;
@@ -1505,17 +1536,48 @@ int ssd_net_train_forward_backward(ssd_net* net, const float* image_dev, int B, 
         if (rc) return rc;
         s.gwritten[l.in] = 1;
     }
-    // VGG16: kernel_regularizer=l2(5e-4) on every backbone / extra conv (models/ssd_vgg16.py:44-45;
-    // the head convs of models/header.py have none): d(5e-4 * sum w^2)/dw = 1e-3 * w
-    if (net->backbone == SSD_VGG16)
-        for (size_t i = 0; i < net->layers.size(); ++i) {
-            const Layer& l = net->layers[i];
-            if (l.kind != LK_CONV || l.head_kind || !s.tl[i].active) continue;
-            const Param& w = net->params[l.p_kernel];
-            hipLaunchKernelGGL(axpy_kernel, dim3(grid_for((long)w.count)), dim3(256), 0, st, grads_flat_dev + s.tl[i].g_kernel,
-                               w.dev, (long)w.count, 2.0f * 5e-4f);
-            SSD_LAUNCH_CHECK();
-        }
+    rc = mark_ready(0);
+    if (rc) return rc;
+    return SSD_OK;
+}
+
+// Gradient buckets for the data-parallel exchange ("prefer ... overlapped with backward"):
+// bucket k covers the flat offsets [lo[k], lo[k + 1]) (lo ascending, lo[0] == 0, the last bucket ends at
+// ssd_net_trainable_floats).  The backward walks the layers last to first, i.e. it finishes the gradient vector
+// from its END; ssd_net_train_forward_backward records an event per bucket at the moment every layer owning a
+// parameter at or above lo[k] has been passed, and ssd_net_train_wait_bucket makes another stream (the one the
+// RCCL all-reduce of that bucket is issued on) wait for exactly that point -- the exchange of the head / extras
+// gradients then runs beside the backward of the backbone.  n == 0 clears the plan.
+int ssd_net_train_set_buckets(ssd_net* net, int n, const long* lo) {
+    SSD_CHECK_ARG(net && n >= 0 && (n == 0 || lo), "ssd_net_train_set_buckets: bad arguments");
+    if (!net->train) { set_error("ssd_net_train_set_buckets: call ssd_net_train_begin() first"); return SSD_E_STATE; }
+    ssd_train_state& s = *net->train;
+    for (int k = 0; k < n; ++k)
+        SSD_CHECK_ARG((k == 0 ? lo[0] == 0 : lo[k] > lo[k - 1]) && lo[k] < (long)s.P, "ssd_net_train_set_buckets: starts must ascend from 0 below %zu", s.P);
+    for (auto e : s.bucket_ev)
+        if (e) (void)hipEventDestroy(e);
+    s.bucket_ev.clear();
+    s.bucket_lo.assign(lo, lo + n);
+    s.pending_hi.clear();
+    if (n == 0) return SSD_OK;
+    s.bucket_ev.resize(n, nullptr);
+    for (int k = 0; k < n; ++k) SSD_HIP(hipEventCreateWithFlags(&s.bucket_ev[k], hipEventDisableTiming));
+    // pending_hi[i] = end of the highest trainable parameter owned by an active layer j <= i
+    s.pending_hi.assign(net->layers.size(), 0);
+    long run = 0;
+    for (size_t i = 0; i < net->layers.size(); ++i) {
+        const Layer& l = net->layers[i];
+        if (s.tl[i].active)
+            for (int q : {l.p_kernel, l.p_bias, l.p_kernel2, l.p_bias2, l.p_bn, l.p_bn >= 0 ? l.p_bn + 1 : -1, l.p_gamma})
+                if (q >= 0 && q < (int)s.poff.size() && s.poff[q] >= 0) run = std::max(run, s.poff[q] + (long)net->params[q].count);
+        s.pending_hi[i] = run;
+    }
+    return SSD_OK;
+}
+
+int ssd_net_train_wait_bucket(ssd_net* net, int k, void* stream) {
+    SSD_CHECK_ARG(net && net->train && k >= 0 && k < (int)net->train->bucket_ev.size(), "ssd_net_train_wait_bucket: bad bucket %d", k);
+    SSD_HIP(hipStreamWaitEvent((hipStream_t)stream, net->train->bucket_ev[k], 0));
     return SSD_OK;
 }
 

@@ -366,12 +366,45 @@ class SSDModel(object):
         floats of THIS rank's batch (Keras logs the batch means; ``loss`` includes the regularisation term,
         the two components do not)."""
         import parallel
+        import torch.distributed as dist
+        multi = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+        n_buckets = int(os.environ.get("SSD_HIP_GRAD_BUCKETS", "4")) if multi else 0
+        if n_buckets > 1:
+            self._plan_gradient_buckets(images.shape[0], n_buckets)
         loc, conf, g = self.forward_backward(images, targets[0], targets[1])
         reg = self.regularization_loss()               # at the weights this batch was evaluated with, like Keras
-        world = parallel.allreduce_gradients(g)
+        if n_buckets > 1:
+            # the exchange of a bucket starts when the backward has finished it (heads / extras first) and runs on
+            # its own stream beside the backward of the backbone
+            lib = _h.lib()
+            world = parallel.allreduce_gradients_as_ready(
+                g, self._bucket_starts,
+                wait_bucket=lambda k, st: _h.check(lib.ssd_net_train_wait_bucket(self._net, k, _h.vp(st.cuda_stream)), "wait_bucket"),
+                comm_stream=self._comm_stream)
+        else:
+            world = parallel.allreduce_gradients(g)
         self.apply_gradients(g, learning_rate, 1.0 / world)
         lm, cm = float(loc.mean().item()), float(conf.mean().item())
         return lm + cm + reg, lm, cm
+
+    def _plan_gradient_buckets(self, batch, n_buckets):
+        """``ssd_net_train_set_buckets``: equal contiguous buckets of the flat gradient, one completion event each."""
+        import parallel
+        lib = _h.lib()
+        if getattr(self, "_train_batch", 0) < batch:
+            _h.check(lib.ssd_net_train_begin(self._net, int(batch)), "ssd_net_train_begin")
+            self._train_batch = int(batch)
+            self._finalized_for = 0
+            self._bucket_starts = None
+        if getattr(self, "_bucket_starts", None) is None or len(self._bucket_starts) != n_buckets:
+            P = lib.ssd_net_trainable_floats(self._net)
+            starts = parallel.bucket_starts(P, n_buckets)
+            arr = (ctypes.c_long * len(starts))(*starts)
+            _h.check(lib.ssd_net_train_set_buckets(self._net, len(starts), arr), "ssd_net_train_set_buckets")
+            self._bucket_starts = starts
+            if getattr(self, "_comm_stream", None) is None:
+                self._comm_stream = _h.new_stream()
+        return self._bucket_starts
 
     def regularization_loss(self):
         """Keras' ``sum(model.losses)``: l2(5e-4) over VGG16's regularised kernels, 0 for MobileNetV2 -- part

@@ -92,6 +92,42 @@ def allreduce_gradients(flat, bucket_floats=None):
     return dist.get_world_size()
 
 
+def bucket_starts(n, n_buckets):
+    """Starts of ``n_buckets`` equal contiguous buckets of a flat vector of ``n`` floats (multiples of 4 floats:
+    16-byte aligned slices); fewer if ``n`` is small."""
+    n_buckets = max(1, min(int(n_buckets), max(1, n // 4)))
+    step = -(-n // n_buckets)
+    step += (-step) % 4
+    return [lo for lo in range(0, n, step)]
+
+
+def allreduce_gradients_as_ready(flat, starts, wait_bucket=None, comm_stream=None):
+    """SUM all-reduce of the flat gradient bucket by bucket IN THE ORDER THE BACKWARD FINISHES THEM: the native
+    backward (``ssd_net_train_forward_backward``) walks the layers last to first and therefore completes the
+    gradient vector from its END (heads and extras first, stem last); bucket k = ``flat[starts[k]:starts[k+1]]``
+    is exchanged as soon as ``wait_bucket(k, comm_stream)`` has ordered ``comm_stream`` behind the bucket's
+    completion event (``ssd_net_train_wait_bucket``), while the backward of the earlier layers is still running
+    on the caller's stream.  xGMI is a point-to-point mesh: a handful of multi-megabyte buckets keeps every
+    message large.  Returns the world size; the caller's stream waits for every bucket before returning."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return 1
+    n = flat.numel()
+    bounds = list(starts) + [n]
+    works = []
+    for k in reversed(range(len(starts))):
+        piece = flat[bounds[k]:bounds[k + 1]]
+        if wait_bucket is not None:
+            wait_bucket(k, comm_stream)
+        if comm_stream is not None:
+            with torch.cuda.stream(comm_stream):      # RCCL's stream orders itself behind the CURRENT stream
+                works.append(dist.all_reduce(piece, op=dist.ReduceOp.SUM, async_op=True))
+        else:
+            works.append(dist.all_reduce(piece, op=dist.ReduceOp.SUM, async_op=True))
+    for w in works:
+        w.wait()
+    return dist.get_world_size()
+
+
 def mean_over_ranks(value):
     """Mean of a host float over all ranks (validation loss of a data-parallel fit)."""
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:

@@ -85,6 +85,8 @@ _SIGNATURES = {
     "ssd_stream_create": (vp, [ctypes.c_int]),
     "ssd_stream_destroy": (ctypes.c_int, [vp]),
     "ssd_net_regularization_loss": (ctypes.c_int, [vp, c_float_p]),
+    "ssd_net_train_set_buckets": (ctypes.c_int, [vp, ctypes.c_int, ctypes.POINTER(ctypes.c_long)]),
+    "ssd_net_train_wait_bucket": (ctypes.c_int, [vp, ctypes.c_int, vp]),
     "ssd_net_num_priors": (ctypes.c_int, [vp]),
     "ssd_net_feature_map_size": (ctypes.c_int, [vp, ctypes.c_int]),
     "ssd_net_forward": (ctypes.c_int, [vp, vp, ctypes.c_int, vp, vp, vp]),
