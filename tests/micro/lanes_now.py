@@ -11,15 +11,17 @@ hp = dict(train_utils.get_hyper_params("mobilenet_v2")); hp["total_labels"] = 21
 m = get_model(hp, max_batch=B)
 data_utils.synthetic_weights(m)
 pri = bbox_utils.generate_prior_boxes(hp["feature_map_shapes"], hp["aspect_ratios"])
+if os.environ.get("LANES_NO_SIDE") == "1":
+    m.set_option("overlap_heads", 0)          # every lane = ONE in-order stream
 dm = get_decoder_model(m, pri, hp, lanes=2)
 x = h.to_dev(data_utils.synthetic_images(B))
 for _ in range(6):
-    dm.submit(x)
+    dm.submit(x, sync_input=False)
 dm.wait(); torch.cuda.synchronize()
 print(getattr(dm, 'lane_calibration', None))
 def t_submit(n):
     torch.cuda.synchronize(); t0 = time.perf_counter()
-    for _ in range(n): dm.submit(x)
+    for _ in range(n): dm.submit(x, sync_input=False)
     dm.wait(); torch.cuda.synchronize()
     return (time.perf_counter() - t0) / n * 1e3
 def t_free(n):

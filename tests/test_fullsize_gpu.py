@@ -275,7 +275,7 @@ def test_two_lanes_match_one_lane():
     outs = [dm2.submit(b) for b in batches]
     dm2.wait()
     torch.cuda.synchronize()
-    assert dm2.lane_calibration["pair"] is not None        # (lanes are opt-in; the stream pair is chosen by measurement)
+    assert "two_lanes_used" in dm2.lane_calibration
     for o, r in zip(outs, ref):
         for a, b in zip(o, r):
             np.testing.assert_array_equal(a.cpu().numpy(), b)
@@ -303,7 +303,7 @@ def test_two_lanes_match_one_lane():
             np.testing.assert_array_equal(a.cpu().numpy(), b)
 
 
-@pytest.mark.parametrize("extra", [[], ["--lanes", "2"], ["--train"]])
+@pytest.mark.parametrize("extra", [[], ["--lanes", "1"], ["--train"]])
 def test_bench_line_contract(extra, tmp_path):
     """`python bench.py --steps K --warmup W` prints ONE JSON line with the driver's keys; value, ms_per_step
     and the batch agree; `roofline` / step figures are self-consistent (small batch: this checks the
@@ -332,9 +332,13 @@ def test_bench_line_contract(extra, tmp_path):
         assert ro["kernel_ms_per_step"] > 0 and 0 < ro["frac_step"] < 1
         dk = ro["dominant_kernel"]
         assert dk["ms_per_launch"] > 0 and 0 < dk["frac"] < 1 and dk["ms_per_launch"] < r["ms_per_step"]
-        # default: one step at a time is the headline, two batches in flight are reported beside it (and vice versa)
-        assert r["config"]["batches_in_flight_per_gpu"] == (2 if extra else 1)
-        assert r["other_mode"]["ms_per_step"] > 0 and ("two batches" in r["other_mode"]["mode"]) == (not extra)
+        # default: two batches in flight (one in-order stream / hardware queue per lane) are the headline, one step at
+        # a time is reported beside it (and vice versa)
+        assert r["config"]["batches_in_flight_per_gpu"] == (1 if extra else 2)
+        assert r["other_mode"]["ms_per_step"] > 0 and ("two batches" in r["other_mode"]["mode"]) == bool(extra)
+        if not extra:
+            lc = r["config"]["lane_calibration"]
+            assert lc["hw_queues"] == "2" and lc["pair"] is None          # no stream-pair search
         assert r["config"]["nms_active"] is True
         kt = r["config"]["kernel_table"]
         assert kt["source"] in ("shipped", "cache", "memo", "autotune") and len(kt["table_sha16"]) == 16

@@ -1,4 +1,5 @@
-export SSD_HIP_TUNE_CACHE=/tmp/tc
-echo "gate=1 wait"; python tests/micro/lanes_now.py 2>&1 | tail -2
-echo "gate=1 nowait"; SSD_DBG_NOWAIT=1 python tests/micro/lanes_now.py 2>&1 | tail -2
-echo "gate=0 nowait"; SSD_HIP_LANE_GATE=0 SSD_DBG_NOWAIT=1 python tests/micro/lanes_now.py 2>&1 | tail -2
+for i in 1 2 3; do python bench.py --no-cpu-baseline 2>/dev/null | python -c "
+import json,sys
+r=json.loads(sys.stdin.read().strip().splitlines()[-1])
+print('value %.0f img/s  %.4f ms/step | other: %.4f ms (%s) | lanes: %s | table: %s' % (r['value'], r['ms_per_step'], r['other_mode']['ms_per_step'], r['other_mode']['mode'][:18], r['config']['lane_calibration'], r['config']['kernel_table']['source']))"; done
+python -m pytest tests/test_fullsize_gpu.py -q -x -k "two_lanes or bench_line" 2>&1 | tail -3
