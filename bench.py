@@ -24,7 +24,8 @@ import time
 # Two batches in flight (--lanes 2) = two in-order streams; with the HIP runtime limited to two hardware queues each
 # lane owns one, reproducibly (DecoderModel).  The variable is read when the runtime starts:
 # it has to be in the environment before torch is imported.  One step at a time is unaffected by it (measured).
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "2")
+if "--train" not in sys.argv:            # (the training step keeps the runtime's default: RCCL brings its own streams)
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "2")
 
 REPO = os.path.dirname(os.path.abspath(__file__))
 for _p in (REPO, os.path.join(REPO, "tf-ssd_amd")):

@@ -111,6 +111,7 @@ struct ssd_net {
     bool launch_raced = false;      // the graph-replay / direct-launch choice was made by a race or a preset line
     // hipGraph replay of a whole forward/predict step, keyed by every pointer baked into it
     bool use_graph = true;
+    bool graphs_unsafe = false;     // GPU_MAX_HW_QUEUES < 4 in the environment: never capture / replay
     bool use_graph_auto = true;     // finalize races graph replay against direct launches (until "use_graph" is set explicitly)
     struct GraphEntry {
         std::vector<const void*> key;

@@ -687,9 +687,18 @@ ssd_net* ssd_net_create(int backbone, int img_size, int levels, const int* n_ars
         }
     if (backbone == SSD_MOBILENET_V2) build_mobilenet_v2(*net);
     else build_vgg16(*net);
+    // hipGraph capture / replay of a step (forks onto the side streams) segfaults inside the HIP runtime when it is
+    // limited to fewer than four hardware queues (GPU_MAX_HW_QUEUES=2, the two-lane serving setup: measured on
+    // ROCm 7.2): such processes launch directly, which is also what the launch-mode race picks at B >= 64
+    if (const char* q = getenv("GPU_MAX_HW_QUEUES"))
+        if (atoi(q) > 0 && atoi(q) < 4) {
+            net->use_graph = false;
+            net->use_graph_auto = false;
+            net->graphs_unsafe = true;
+        }
     if (const char* g = getenv("SSD_TAIL_PRIO")) net->tail_prio = atoi(g) < 0 ? 0 : (atoi(g) > 2 ? 2 : atoi(g));    // diagnostics
     if (const char* g = getenv("SSD_HIP_USE_GRAPH")) {      // diagnostics: pin the launch mode (0 direct, 1 graph replay)
-        net->use_graph = atoi(g) != 0;
+        net->use_graph = atoi(g) != 0 && !net->graphs_unsafe;
         net->use_graph_auto = false;
     }
     return net.release();
@@ -1411,6 +1420,10 @@ int ssd_net_set_option(ssd_net* net, const char* name, int value) {
         return SSD_OK;
     }
     if (std::string(name) == "use_graph") {
+        if (value && net->graphs_unsafe) {
+            set_error("ssd_net_set_option: use_graph 1 is not available with GPU_MAX_HW_QUEUES < 4 (hipGraph replay of the forked step crashes in the runtime)");
+            return SSD_E_UNSUPPORTED;
+        }
         net->use_graph = value != 0;
         net->use_graph_auto = false;
         net->drop_graphs();
