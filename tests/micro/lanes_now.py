@@ -13,9 +13,10 @@ data_utils.synthetic_weights(m)
 pri = bbox_utils.generate_prior_boxes(hp["feature_map_shapes"], hp["aspect_ratios"])
 if os.environ.get("LANES_NO_SIDE") == "1":
     m.set_option("overlap_heads", 0)          # every lane = ONE in-order stream
-dm = get_decoder_model(m, pri, hp, lanes=2)
+NL = int(os.environ.get('LANES', '2'))
+dm = get_decoder_model(m, pri, hp, lanes=NL)
 x = h.to_dev(data_utils.synthetic_images(B))
-for _ in range(6):
+for _ in range(3 * NL):
     dm.submit(x, sync_input=False)
 dm.wait(); torch.cuda.synchronize()
 print(getattr(dm, 'lane_calibration', None))
@@ -29,8 +30,8 @@ def t_free(n):
     ms, ss = dm._lane_models, dm._lane_streams
     torch.cuda.synchronize(); t0 = time.perf_counter()
     for i in range(n):
-        with torch.cuda.stream(ss[i % 2]):
-            ms[i % 2].predict_on_device(x, d.prior_boxes, d.variances, max_total=d.max_total_size, iou_threshold=d.iou_threshold, score_threshold=d.score_threshold)
+        with torch.cuda.stream(ss[i % NL]):
+            ms[i % NL].predict_on_device(x, d.prior_boxes, d.variances, max_total=d.max_total_size, iou_threshold=d.iou_threshold, score_threshold=d.score_threshold)
     torch.cuda.synchronize()
     return (time.perf_counter() - t0) / n * 1e3
 def t_seq(n):

@@ -279,6 +279,14 @@ def test_two_lanes_match_one_lane():
     for o, r in zip(outs, ref):
         for a, b in zip(o, r):
             np.testing.assert_array_equal(a.cpu().numpy(), b)
+    dm3 = get_decoder_model(m, priors, hp, lanes=3)            # three replicas: still every step's own result, in order
+    outs3 = [dm3.submit(b) for b in batches]
+    dm3.wait()
+    torch.cuda.synchronize()
+    for o, r in zip(outs3, ref):
+        for a, b in zip(o, r):
+            np.testing.assert_array_equal(a.cpu().numpy(), b)
+    del dm3
     stacked = np.concatenate(batches)
     p1 = dm1.predict(stacked, batch_size=6)
     p2 = dm2.predict(stacked, batch_size=6)
@@ -334,11 +342,11 @@ def test_bench_line_contract(extra, tmp_path):
         assert dk["ms_per_launch"] > 0 and 0 < dk["frac"] < 1 and dk["ms_per_launch"] < r["ms_per_step"]
         # default: two batches in flight (one in-order stream / hardware queue per lane) are the headline, one step at
         # a time is reported beside it (and vice versa)
-        assert r["config"]["batches_in_flight_per_gpu"] == (1 if extra else 2)
-        assert r["other_mode"]["ms_per_step"] > 0 and ("two batches" in r["other_mode"]["mode"]) == bool(extra)
+        assert r["config"]["batches_in_flight_per_gpu"] == (1 if extra else 3)
+        assert r["other_mode"]["ms_per_step"] > 0 and ("three batches" in r["other_mode"]["mode"]) == bool(extra)
         if not extra:
             lc = r["config"]["lane_calibration"]
-            assert lc["hw_queues"] == "2" and lc["pair"] is None          # no stream-pair search
+            assert lc["hw_queues"] == "3" and lc["pair"] is None          # one hardware queue per lane, no stream-pair search
         assert r["config"]["nms_active"] is True
         kt = r["config"]["kernel_table"]
         assert kt["source"] in ("shipped", "cache", "memo", "autotune") and len(kt["table_sha16"]) == 16

@@ -96,14 +96,18 @@ class DecoderModel(object):
         # Two lanes = two replicas of the net, each on ONE in-order non-blocking stream (ssd_stream_create; no intra-step
         # side streams).  With the HIP runtime limited to two hardware queues (environment GPU_MAX_HW_QUEUES=2, read
         # when the runtime starts -- bench.py sets it before importing torch) each lane owns a hardware queue and the
-        # GPU interleaves the two command streams: 1.60 ms per step at B=64 against 1.79 one step at a time, reproducibly
-        # and without choosing streams by measurement.  With the runtime's default of four queues the outcome depends
+        # GPU interleaves the command streams: 1.60 ms per step at B=64 with two lanes / two queues, 1.51-1.53 ms with three
+        # lanes / three queues, against 1.79 one step at a time -- reproducibly, without choosing streams by measurement.  With the runtime's default of four queues the outcome depends
         # on which queues the streams happen to share (measured: 1.61 ms on the best pair, 2.2-2.3 ms -- worse than one
         # lane -- on an arbitrary pair): there the pair is chosen by measurement on the first submit
         # (SSD_HIP_LANE_CALIBRATE=1 forces, =0 forbids that).  Either way a short check on the first submit falls back
         # to one lane if two do not pay.
+        # (N lanes on N hardware queues, measured at B=64: 2 / 2 1.60 ms, 3 / 3 1.51-1.53 ms, 3 lanes on 2 queues 1.67,
+        # 2 or 4 lanes on 3 queues 1.60; from four queues up the submit loop degrades -- 2.1-3.0 ms -- although a bare
+        # launch loop still reaches 1.52-1.6: tests/micro/lanes_now.py)
         cal = os.environ.get("SSD_HIP_LANE_CALIBRATE")
-        self.calibrate = (cal == "1") if cal is not None else os.environ.get("GPU_MAX_HW_QUEUES") != "2"
+        q = os.environ.get("GPU_MAX_HW_QUEUES", "")
+        self.calibrate = (cal == "1") if cal is not None else not (q.isdigit() and 1 < int(q) < 4)
 
     def _lane(self, i):
         """(model, stream) of lane i; replicas are (re)built when the base model's weights changed."""
@@ -191,8 +195,8 @@ class DecoderModel(object):
             torch.cuda.synchronize()
             return (time.perf_counter() - t0) / n
 
-        run(4, 2)                                   # both replicas finalized / warm
-        two = run(16, 2)
+        run(2 * self.lanes, self.lanes)             # every replica finalized / warm
+        two = run(8 * self.lanes, self.lanes)
         one = run(8, 1)
         self._lanes_active = two < 0.985 * one
         self._lanes_calibrated = True
@@ -212,10 +216,10 @@ class DecoderModel(object):
         d = self.decoder
         x = _h.to_dev(images)
         self.base_model._ensure(x.shape[0])            # the replicas inherit the base model's kernel table
-        if self.lanes == 2 and not self._lanes_calibrated:
-            self._lane(0)
-            self._lane(1)
-            if self.calibrate:
+        if self.lanes >= 2 and not self._lanes_calibrated:
+            for k in range(self.lanes):
+                self._lane(k)
+            if self.calibrate and self.lanes == 2:
                 self._calibrate_lane_streams(x)
             else:
                 self._check_lanes_pay(x)
