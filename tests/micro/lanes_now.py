@@ -13,6 +13,17 @@ data_utils.synthetic_weights(m)
 pri = bbox_utils.generate_prior_boxes(hp["feature_map_shapes"], hp["aspect_ratios"])
 if os.environ.get("LANES_NO_SIDE") == "1":
     m.set_option("overlap_heads", 0)          # every lane = ONE in-order stream
+edit = os.environ.get("LANE_TABLE_EDIT")        # e.g. "1_conv_heads=1,2_conv_heads=1": split-K overrides for the lanes' table
+if edit:
+    m._ensure(B)
+    base_get = m.get_tuning
+    def edited():
+        t = base_get()
+        for kv in edit.split(","):
+            name, split = kv.split("=")
+            t = "\n".join((" ".join(l.split()[:2] + [split]) if l.split() and l.split()[0] == name else l) for l in t.splitlines()) + "\n"
+        return t
+    m.get_tuning = edited
 NL = int(os.environ.get('LANES', '2'))
 dm = get_decoder_model(m, pri, hp, lanes=NL)
 x = h.to_dev(data_utils.synthetic_images(B))

@@ -470,7 +470,8 @@ int image_block_groups(const FusedBlockParams& p, int B) {
     }
     const int units = p.Ce / kIC;
     int best = 1;
-    for (int g = 1; g <= 12 && g <= units; ++g) {
+    static const int cap = getenv("SSD_IMAGE_GROUPS_CAP") ? atoi(getenv("SSD_IMAGE_GROUPS_CAP")) : 12;   // diagnostics
+    for (int g = 1; g <= 12 && g <= units && g <= cap; ++g) {
         if (units % g) continue;
         best = g;
         if ((long)B * g * 8 >= (long)num_cu * 7) break;

@@ -1,7 +1,7 @@
-for i in 1 2 3; do python bench.py --no-cpu-baseline 2>/dev/null | python -c "
-import json,sys
-r=json.loads(sys.stdin.read().strip().splitlines()[-1])
-print('value %.0f img/s  %.4f ms/step | other: %.4f ms (%s) | lanes: %s' % (r['value'], r['ms_per_step'], r['other_mode']['ms_per_step'], r['other_mode']['mode'][:18], r['config']['lane_calibration']))"; done
-python bench.py --lanes 2 --no-cpu-baseline 2>/dev/null | cut -c1-200
-python bench.py --lanes 1 --no-cpu-baseline 2>/dev/null | cut -c1-330
-python -m pytest tests/test_fullsize_gpu.py -q -x -k "two_lanes or bench_line" 2>&1 | tail -3
+export SSD_HIP_LANE_CALIBRATE=0 GPU_MAX_HW_QUEUES=3 LANES=3
+echo base; python tests/micro/lanes_now.py 2>&1 | tail -1
+echo "heads split 1"; LANE_TABLE_EDIT="1_conv_heads=1,2_conv_heads=1" python tests/micro/lanes_now.py 2>&1 | tail -1
+echo "heads split 2"; LANE_TABLE_EDIT="1_conv_heads=2,2_conv_heads=2" python tests/micro/lanes_now.py 2>&1 | tail -1
+echo "image groups cap 1"; SSD_IMAGE_GROUPS_CAP=1 python tests/micro/lanes_now.py 2>&1 | tail -1
+echo "image groups cap 2"; SSD_IMAGE_GROUPS_CAP=2 python tests/micro/lanes_now.py 2>&1 | tail -1
+echo "cap 2 + heads split 2"; SSD_IMAGE_GROUPS_CAP=2 LANE_TABLE_EDIT="1_conv_heads=2,2_conv_heads=2" python tests/micro/lanes_now.py 2>&1 | tail -1
