@@ -34,8 +34,8 @@ for v in (0, 1, 0, 1):
     outs[v] = (d.cpu().numpy(), p.cpu().numpy(), m.fetch_activation("block_6_project_BN") if False else None)
     tot = 0.0
     for rec in m.profile_layers(x, reps=10):
-        if rec["ms"] > 0 and rec["kind"] == "fused" and rec["name"].split("_")[0] == "block" and int(rec["name"].split("_")[1]) <= 6:
+        if rec["ms"] > 0 and rec["kind"] == "fused" and (rec["name"].startswith("stem") or (rec["name"].split("_")[0] == "block" and int(rec["name"].split("_")[1]) <= 6)):
             print("   %-24s %.4f ms  %6.1f TF/s" % (rec["name"], rec["ms"], rec["flops"] / rec["ms"] / 1e9))
             tot += rec["ms"]
-    print("   blocks 1-6 total %.4f ms" % tot, flush=True)
+    print("   stem + blocks 1-6 total %.4f ms" % tot, flush=True)
 print("max |d probs| band vs tile: %.3e   max |d deltas|: %.3e" % (np.abs(outs[0][1] - outs[1][1]).max(), np.abs(outs[0][0] - outs[1][0]).max()))
