@@ -85,6 +85,12 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        # RCCL creates its communicator (and its own streams) at the first collective: do that NOW, before the lanes'
+        # streams exist, so that it cannot disturb which hardware queue each lane gets
+        _t = torch.zeros(1, device="cuda")
+        dist.all_reduce(_t)
+        dist.barrier()
+        torch.cuda.synchronize()
 
     import ssd_hip
     from utils import bbox_utils, train_utils, data_utils
