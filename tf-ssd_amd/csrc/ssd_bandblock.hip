@@ -62,7 +62,11 @@ __global__ __launch_bounds__(kBThreads) void mbv2_band_block_kernel(const FusedB
     const int tid = threadIdx.x, lane = tid & 63, l15 = lane & 15, g4 = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);       // scalar: the tile-count tests below are s_cbranch, not exec masks
     const int nb = p.bands;
-    const int img = blockIdx.x / nb, band = blockIdx.x - img * nb;
+    // XCD-aware item order: hardware deals consecutive workgroup ids round-robin over the 8 XCDs (own L2 each); the
+    // bands of one image -- which share their halo rows of x -- get ids that land on the same XCD
+    const int items = p.B * nb;
+    const int bid = (items & 7) == 0 ? (int)(blockIdx.x & 7) * (items >> 3) + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+    const int img = bid / nb, band = bid - img * nb;
     const int H = p.H, W = p.W, Ho = p.Ho, Wo = p.Wo, Ce = p.Ce;
     const int ro0 = band * Ho / nb, R = (band + 1) * Ho / nb - ro0;
     const int ri0 = S * ro0 - p.pad_t;            // first input row of the band (may be -1)
