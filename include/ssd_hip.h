@@ -162,8 +162,10 @@ typedef struct ssd_conv_desc {
 int ssd_same_pads(int in, int k, int stride, int dilation, int* before, int* after);
 int ssd_conv_out_size(int in, int k, int stride, int dilation, int pad_before, int pad_after);
 
-/* Packed dense-conv weights: [Npad][Kpad] fp32, K = (ky*kw+kx)*Cin+ci, zero padded
- * (device).  scale/shift [Cout] are the folded BatchNorm (or 1/bias) epilogue vectors. */
+/* Packed dense-conv weights: [Npad][Kpad] fp32, K = (ky*kw+kx)*Cin+ci, zero padded (device), followed by the
+ * same matrix split EXACTLY into three bf16 planes [3][Npad][Kpad] (x = h + m + l; the "mfma3_*" tile configs run
+ * every product as six bf16 MFMAs at fp32 accuracy, csrc/ssd_bf16x3.h).  ssd_conv_packed_weight_floats() covers
+ * both.  scale/shift [Cout] are the folded BatchNorm (or 1/bias) epilogue vectors. */
 size_t ssd_conv_packed_weight_floats(int kh, int kw, int Cin, int Cout);
 int ssd_conv_pack_weights(const float* hwio_dev, int kh, int kw, int Cin, int Cout,
                           float* packed_dev, void* stream);

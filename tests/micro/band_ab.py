@@ -17,7 +17,7 @@ pri = bbox_utils.generate_prior_boxes(hp["feature_map_shapes"], hp["aspect_ratio
 dm = get_decoder_model(m, pri, hp)
 x = h.to_dev(data_utils.synthetic_images(B))
 outs = {}
-for v in (0, 1, 0, 1):
+for v in (0, 1, 2, 1, 2):
     m.set_option("fuse_band", v)
     for _ in range(10):
         dm(x)
@@ -39,3 +39,4 @@ for v in (0, 1, 0, 1):
             tot += rec["ms"]
     print("   stem + blocks 1-6 total %.4f ms" % tot, flush=True)
 print("max |d probs| band vs tile: %.3e   max |d deltas|: %.3e" % (np.abs(outs[0][1] - outs[1][1]).max(), np.abs(outs[0][0] - outs[1][0]).max()))
+print("max |d probs| split-bf16 band vs fp32 band: %.3e   max |d deltas|: %.3e" % (np.abs(outs[2][1] - outs[1][1]).max(), np.abs(outs[2][0] - outs[1][0]).max()))

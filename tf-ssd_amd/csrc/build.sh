@@ -12,7 +12,7 @@ compile() {  # src extra-flags
   local src=$1; shift
   local obj=build/${src%.*}.o
   if [ "$FORCE" = 1 ] || [ ! -f "$obj" ] || [ "$src" -nt "$obj" ] || [ common.h -nt "$obj" ] \
-     || [ ../../include/ssd_hip.h -nt "$obj" ] || [ ssd_conv.h -nt "$obj" ] || [ ssd_net.h -nt "$obj" ] || { [ -f "${src%.*}.h" ] && [ "${src%.*}.h" -nt "$obj" ]; }; then
+     || [ ../../include/ssd_hip.h -nt "$obj" ] || [ ssd_conv.h -nt "$obj" ] || [ ssd_net.h -nt "$obj" ] || [ ssd_conv_mfma.h -nt "$obj" ] || [ ssd_bf16x3.h -nt "$obj" ] || { [ -f "${src%.*}.h" ] && [ "${src%.*}.h" -nt "$obj" ]; }; then
     echo "hipcc $src"
     # translation units compile in parallel (ssd_conv.hip alone instantiates ~80 kernels)
     ( $HIPCC $COMMON "$@" -c "$src" -o "$obj.tmp" && mv "$obj.tmp" "$obj" ) || touch build/.failed &
@@ -31,7 +31,7 @@ compile ssd_bbox.hip -ffp-contract=off -fhip-fp32-correctly-rounded-divide-sqrt
 # loss: separately rounded ops too (the hard-negative RANK depends on the per-anchor CE values)
 compile ssd_loss.hip -ffp-contract=off -fhip-fp32-correctly-rounded-divide-sqrt
 compile ssd_data.hip -ffp-contract=off -fhip-fp32-correctly-rounded-divide-sqrt
-for s in ssd_conv.hip ssd_wino.hip ssd_skinny.hip ssd_ops.hip ssd_fused.hip ssd_bandblock.hip ssd_imgblock.hip ssd_dwproj.hip ssd_net.hip ssd_train.hip; do
+for s in ssd_conv.hip ssd_conv3.hip ssd_wino.hip ssd_skinny.hip ssd_ops.hip ssd_fused.hip ssd_bandblock.hip ssd_band3.hip ssd_imgblock.hip ssd_dwproj.hip ssd_net.hip ssd_train.hip; do
   [ -f "$s" ] && compile "$s"
 done
 wait

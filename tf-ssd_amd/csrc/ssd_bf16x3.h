@@ -1,0 +1,71 @@
+// FP32 products on the BF16 matrix cores (gfx950): every fp32 operand is split EXACTLY into three bf16 pieces,
+//
+//     x = h + m + l,   h = x & 0xffff0000,  m = (x - h) & 0xffff0000,  l = x - h - m      (8 + 8 + 8 significand bits)
+//     x * y = hh + hm + mh + hl + lh + mm  (+ ml + lm + ll, dropped: <= ~2^-23 |x y|, the size of ONE fp32 rounding)
+//
+// i.e. six v_mfma_f32_16x16x32_bf16 with fp32 accumulation replace eight v_mfma_f32_16x16x4_f32 per 16 x 16 x 32 block.
+// Measured (tests/micro/bf16x3_mfma.hip): error vs float64 2.3e-6 against 3.2e-6 for the fp32 MFMA chain on |D| <= 22
+// (as accurate as the fp32 instruction), 404 TFLOP/s fp32-equivalent against 151 (2.67x), and -- the point on gfx950,
+// where the f32-input MFMA runs at the VECTOR rate and shares the VALU's issue -- the bf16 MFMAs overlap with a
+// kernel's VALU / LDS work instead of adding to it.  Results are not bit-identical to the fp32-MFMA kernels (another,
+// equally valid, rounding of the same sums).
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace ssd {
+
+typedef float b3_f32x4 __attribute__((ext_vector_type(4)));
+typedef short bf16x8 __attribute__((ext_vector_type(8)));
+
+struct B3 {
+    bf16x8 h, m, l;
+};
+
+__device__ __forceinline__ void split1(float x, short& h, short& m, short& l) {
+    const unsigned hb = __float_as_uint(x) & 0xffff0000u;
+    const float r1 = x - __uint_as_float(hb);
+    const unsigned mb = __float_as_uint(r1) & 0xffff0000u;
+    const float r2 = r1 - __uint_as_float(mb);
+    h = (short)(hb >> 16);
+    m = (short)(mb >> 16);
+    l = (short)(__float_as_uint(r2) >> 16);
+}
+// four k-values -> 4 bf16 (8 bytes) per plane; pair packing with v_perm_b32 (upper halves of two dwords)
+__device__ __forceinline__ void split4(const b3_f32x4 v, uint2& h, uint2& m, uint2& l) {
+    unsigned hb[4], mb[4], lb[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        hb[j] = __float_as_uint(v[j]) & 0xffff0000u;
+        const float r1 = v[j] - __uint_as_float(hb[j]);
+        mb[j] = __float_as_uint(r1) & 0xffff0000u;
+        lb[j] = __float_as_uint(r1 - __uint_as_float(mb[j]));
+    }
+    h = make_uint2(__builtin_amdgcn_perm(hb[1], hb[0], 0x07060302u), __builtin_amdgcn_perm(hb[3], hb[2], 0x07060302u));
+    m = make_uint2(__builtin_amdgcn_perm(mb[1], mb[0], 0x07060302u), __builtin_amdgcn_perm(mb[3], mb[2], 0x07060302u));
+    l = make_uint2(__builtin_amdgcn_perm(lb[1], lb[0], 0x07060302u), __builtin_amdgcn_perm(lb[3], lb[2], 0x07060302u));
+}
+// lane's 8 k-values (a = k 0..3, b = k 4..7) -> the three bf16 fragments
+__device__ __forceinline__ B3 split3(const b3_f32x4 a, const b3_f32x4 b) {
+    B3 r;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        short h, m, l;
+        split1(a[j], h, m, l);
+        r.h[j] = h; r.m[j] = m; r.l[j] = l;
+        split1(b[j], h, m, l);
+        r.h[4 + j] = h; r.m[4 + j] = m; r.l[4 + j] = l;
+    }
+    return r;
+}
+// acc += W * X over one K = 32 step, six products, small terms first
+__device__ __forceinline__ b3_f32x4 mma6(const B3& w, const B3& x, b3_f32x4 acc) {
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w.m, x.m, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w.h, x.l, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w.l, x.h, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w.h, x.m, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w.m, x.h, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w.h, x.h, acc, 0, 0, 0);
+    return acc;
+}
+
+}  // namespace ssd

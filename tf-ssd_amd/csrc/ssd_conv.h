@@ -10,6 +10,7 @@ namespace ssd {
 struct ConvParams {
     const float* in;
     const float* w;        // packed [Npad][Kpad]
+    const short* w3;       // the same split exactly into three bf16 planes [3][Npad][Kpad] (ssd_conv3.hip) or nullptr
     const float* scale;    // [Cout] or nullptr (== 1)
     const float* shift;    // [Cout] or nullptr (== 0)
     const float* residual; // dense [M][Cout] or nullptr
@@ -48,6 +49,8 @@ struct FusedBlockParams {
     int tiles_y, tiles_x;       // filled by the launcher
     // whole-image kernel (csrc/ssd_imgblock.hip): expanded-channel groups per image and their meeting point
     int groups;                 // G >= 1 (filled by the caller from image_block_groups)
+    const short* we3;           // split-bf16 band kernel (csrc/ssd_band3.hip): bf16 planes of we [3][Ce][32] ...
+    const short* wp3;           // ... and of wp [3][npad_p][pairs][4][8]
     int bands;                  // row-band kernel (csrc/ssd_bandblock.hip): bands per image (filled by the launcher)
     float* slabs;               // [G][B][Ho*Wo][Cout] partial sums (G > 1)
     unsigned* tickets;          // [B] arrival counters, zero between launches
@@ -90,6 +93,12 @@ bool stem_supported(const StemParams& p);
 int launch_stem(StemParams p, hipStream_t st);
 bool fused_block_supported(const FusedBlockParams& p);
 int launch_fused_block(FusedBlockParams p, hipStream_t st);
+bool band3_block_supported(const FusedBlockParams& p);
+size_t band3_we_shorts(int Ce);
+size_t band3_wp_shorts(int npad_p, int Ce);
+int launch_band3_pack(const float* we, int Ce, int Cin, int kpad_e, short* we3, const float* wp, int npad_p, int kpad_p,
+                      short* wp3, hipStream_t st);
+int launch_band3_block(FusedBlockParams p, hipStream_t st);
 bool band_block_supported(const FusedBlockParams& p);
 int launch_band_block(FusedBlockParams p, hipStream_t st);
 bool image_block_supported(const FusedBlockParams& p);
@@ -134,6 +143,14 @@ bool skinny_config_valid(int i, const ConvParams& p);
 long skinny_grid_blocks(int i, const ConvParams& p);
 int skinny_launch(const ConvParams& p, int i, hipStream_t st);
 
+// Split-bf16 implicit-GEMM tiles (csrc/ssd_conv3.hip); config ids behind the skinny ones
+int mfma3_num_configs();
+const char* mfma3_config_name(int i);
+bool mfma3_config_valid(int i, const ConvParams& p);
+long mfma3_grid_blocks(int i, const ConvParams& p);
+int mfma3_k_tiles(const ConvParams& p);
+int mfma3_launch(const ConvParams& p, int i, hipStream_t st);
+
 int launch_dwconv3x3(const float* in, int B, int H, int W, int C, int stride, int pad_t, int pad_l,
                      int Ho, int Wo, const float* w, const float* scale, const float* shift, int act,
                      float* out, hipStream_t st);
@@ -142,6 +159,15 @@ int launch_maxpool(const float* in, int B, int H, int W, int C, int k, int strid
 int launch_l2norm(const float* in, long pixels, int C, const float* gamma, float* out, hipStream_t st);
 int launch_softmax(const float* in, long rows, int L, float* out, hipStream_t st);
 int launch_pack_weights(const float* hwio, int K, int Cout, int Kpad, int Npad, float* packed, hipStream_t st);
+// packed fp32 weights + room for their three bf16 planes (conv_split_planes points at them)
+inline size_t conv_packed_floats(int K, int Cout) {
+    const size_t n = (size_t)conv_kpad(K) * conv_npad(Cout);
+    return n + (3 * n + 1) / 2;
+}
+inline const short* conv_split_planes(const float* packed, int K, int Cout) {
+    return reinterpret_cast<const short*>(packed + (size_t)conv_kpad(K) * conv_npad(Cout));
+}
+int launch_pack_split(float* packed, int K, int Cout, hipStream_t st);     // after ALL launch_pack_weights calls of a buffer
 // out[r][c] = in[r][c] * scale[r] (rows >= nvalid copied unscaled); out[r][c] = in[r][c] * scale[c]
 int launch_scale_rows(const float* in, const float* scale, int rows, int nvalid, int cols, float* out, hipStream_t st);
 int launch_scale_cols(const float* in, const float* scale, int rows, int cols, float* out, hipStream_t st);

@@ -22,349 +22,11 @@
 //   * The epilogue writes through (batch stride, pixel stride) so the SSD head convs store
 //     straight into the concatenated [B, N, K] buffers (reference models/header.py:34-41).
 #include "ssd_conv.h"
+#include "ssd_conv_mfma.h"
 
 namespace ssd {
 
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-
-__device__ __forceinline__ float apply_act(float v, int act) {
-    if (act == SSD_ACT_RELU) return fmaxf(v, 0.0f);
-    if (act == SSD_ACT_RELU6) return fminf(fmaxf(v, 0.0f), 6.0f);
-    return v;
-}
-
-// Diagnostic builds only (tests/micro/conv_ablate.py): -DSSD_CONV_ABLATE=bits removes one phase
-// of the main loop -- 1 global loads, 2 LDS stores, 4 MFMAs (+ fragment reads), 8 barriers,
-// 16 MFMAs only (fragment reads kept),
-// 64 LDS-only raw barrier.  0 = the production kernel.
-#ifndef SSD_CONV_ABLATE
-#define SSD_CONV_ABLATE 0
-#endif
-
-template <int MT, int NT, int WM, int WN, int BK, bool GEMM1X1>
-__global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvParams p) {
-    constexpr int BM = 16 * MT * WM, BN = 16 * NT * WN;
-    // LDS tile rows: BK >= 32 uses UNPADDED rows with an XOR swizzle of the 16-byte column index,
-    // col ^ f(row) with f = (row >> 1) & 7 (BK 32) / row & 15 (BK 64).  Under gfx950's actual
-    // ds_read_b128 / ds_write_b128 lane grouping ({0-3,12-15,20-27}, {4-11,16-19,28-31}, ...) this
-    // is conflict-free for the fragment reads AND the tile writes, whereas rows padded to BK + 4
-    // are 2-way conflicted on both (SQ_LDS_BANK_CONFLICT was exactly 1/3 of SQ_LDS_IDX_ACTIVE
-    // for every config) -- and it takes 11 % less LDS.  BK = 16 keeps the padded rows.
-    constexpr bool SWZ = BK >= 32;
-    constexpr int LDK = SWZ ? BK : BK + 4;
-    constexpr int UPR = BK / 4;                 // float4 units per tile row
-    constexpr int XU = BM * UPR, WU = BN * UPR;
-    constexpr int XP = (XU + 255) / 256, WP = (WU + 255) / 256;
-    static_assert(WM * WN == 4, "4 waves per block");
-    // two LDS stages: tile kt+1 is written while tile kt is multiplied -> one barrier per K tile
-    __shared__ __attribute__((aligned(16))) float smem[2 * (BM + BN) * LDK];
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave / WN, wn = wave % WN;
-    const int nb_n = (p.Cout + BN - 1) / BN;
-    const int mblk = blockIdx.x / nb_n, nblk = blockIdx.x - mblk * nb_n;
-    const long m0 = (long)mblk * BM;
-    const int n0 = nblk * BN;
-    const int HoWo = p.Ho * p.Wo;
-
-    // ---- per-thread load bookkeeping (rows are the same for every K tile)
-    // Addresses are (block base pointer, uniform) + (per-row byte offset, VGPR) + (per-tile byte
-    // offset, SGPR): a load costs an add and a select in the loop.  Lanes whose element is
-    // padding / out of range read offset 0 of the block base (always mapped) and the value is
-    // replaced by zero when the tile is written to LDS -- the loop body has no divergent branch.
-    const int b_first = (int)m0 / HoWo;
-    const char* xbase = reinterpret_cast<const char*>(p.in + (GEMM1X1 ? m0 * p.Cin : (long)b_first * p.H * p.W * p.Cin));
-    const char* wbase = reinterpret_cast<const char*>(p.w + (long)n0 * p.Kpad);
-    int xoff[XP];              // bytes, relative to xbase (may be negative on padded taps: those are invalid)
-    unsigned xvalid[XP];       // general: bit t = tap t of this row lies inside the image; 1x1: row valid
-    int woff[WP];              // bytes, relative to wbase
-    const float* xrow1[XP];    // 1x1 path: plain row pointers + predicated loads measured faster there
-#pragma unroll
-    for (int ps = 0; ps < XP; ++ps) {
-        const int u = tid + ps * 256;
-        const int row = u / UPR;
-        const long m = m0 + row;
-        const bool ok = (u < XU) && (m < p.M);
-        xvalid[ps] = 0;
-        xoff[ps] = 0;
-        if (GEMM1X1) {
-            xvalid[ps] = ok ? 1u : 0u;
-            xrow1[ps] = p.in + (ok ? m : 0) * p.Cin + (tid % UPR) * 4;
-        } else if (ok) {
-            const int b = (int)m / HoWo;              // M < 2^31 (host check)
-            const int pix = (int)m - b * HoWo;
-            const int oy = pix / p.Wo, ox = pix - oy * p.Wo;
-            const int iy0 = oy * p.stride - p.pad_t, ix0 = ox * p.stride - p.pad_l;
-            xoff[ps] = ((((b - b_first) * p.H + iy0) * p.W + ix0) * p.Cin + (tid % UPR) * 4) * 4;
-            for (int ky = 0; ky < p.kh; ++ky)
-                for (int kx = 0; kx < p.kw; ++kx) {
-                    const int iy = iy0 + ky * p.dil, ix = ix0 + kx * p.dil;
-                    if ((unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W) xvalid[ps] |= 1u << (ky * p.kw + kx);
-                }
-        }
-    }
-#pragma unroll
-    for (int ps = 0; ps < WP; ++ps) {
-        const int u = tid + ps * 256;
-        const int r = min(u / UPR, min(BN, p.Npad - n0) - 1);     // clamped: rows past the tile / Npad are never used
-        woff[ps] = (r * p.Kpad + (tid % UPR) * 4) * 4;
-    }
-    const int kq4 = (tid % UPR) * 4;           // identical for every pass (256 % UPR == 0)
-
-    const int nkt_total = (p.K + BK - 1) / BK;
-    int kt_begin = 0, kt_end = nkt_total;
-    if (p.split_k > 1) {
-        const int per = (nkt_total + p.split_k - 1) / p.split_k;
-        kt_begin = blockIdx.y * per;
-        kt_end = min(nkt_total, kt_begin + per);
-    }
-
-    // uniform state of the tile being loaded: k0, its tap (general path) and byte offsets
-    int l_k0 = 0, l_tap = 0, l_ci = 0, l_ky = 0, l_kx = 0, l_xtile = 0;
-    // General path: the K tiles are walked channel-slice-major, taps innermost -- tile t covers
-    // tap t % (kh*kw) of input channels [(t / (kh*kw)) * BK, +BK).  The kh*kw taps of one channel
-    // slice re-read the same 128-byte pixel lines, so they hit in L1/L2 back to back; with the
-    // tap-major order (whole Cin per tap) every tap re-fetched the block's input region from
-    // the fabric (FETCH_SIZE of the 3x3 head conv: 6.7x its algorithmic bytes).
-    const int ntaps = p.kh * p.kw;
-    auto tile_setup = [&](int kt) {            // once; afterwards tile_advance()
-        if (GEMM1X1) {
-            l_k0 = kt * BK;
-            l_xtile = l_k0 * 4;
-        } else {
-            const int cs = kt / ntaps;
-            l_tap = kt - cs * ntaps;
-            l_ci = cs * BK;
-            l_ky = l_tap / p.kw;
-            l_kx = l_tap - l_ky * p.kw;
-            l_k0 = l_tap * p.Cin + l_ci;
-            l_xtile = ((l_ky * p.dil * p.W + l_kx * p.dil) * p.Cin + l_ci) * 4;
-        }
-    };
-    auto tile_advance = [&]() {                // kt -> kt + 1 (Cin % BK == 0 on the general path)
-        if (GEMM1X1) {
-            l_k0 += BK;
-            l_xtile += BK * 4;
-        } else {
-            ++l_tap;
-            if (++l_kx == p.kw) { l_kx = 0; ++l_ky; }
-            if (l_tap == ntaps) { l_tap = 0; l_ky = 0; l_kx = 0; l_ci += BK; }
-            l_k0 = l_tap * p.Cin + l_ci;
-            l_xtile = ((l_ky * p.dil * p.W + l_kx * p.dil) * p.Cin + l_ci) * 4;
-        }
-    };
-    auto x_is_valid = [&](int ps) -> bool {
-        if (GEMM1X1) return xvalid[ps] && (l_k0 + kq4 < p.K);
-        return (xvalid[ps] >> l_tap) & 1u;
-    };
-
-    f32x4 xr[XP], wr[WP];
-    auto load_tile = [&]() {                   // the tile described by the l_* state
-        if (SSD_CONV_ABLATE & 1) return;
-#pragma unroll
-        for (int ps = 0; ps < XP; ++ps) {
-            if (GEMM1X1) {
-                xr[ps] = f32x4{0.f, 0.f, 0.f, 0.f};
-                if (x_is_valid(ps)) xr[ps] = *reinterpret_cast<const f32x4*>(xrow1[ps] + l_k0);
-            } else {
-                const int off = x_is_valid(ps) ? xoff[ps] + l_xtile : 0;
-                xr[ps] = *reinterpret_cast<const f32x4*>(xbase + (unsigned)off);     // valid offsets are >= 0: SGPR base + u32 offset
-            }
-        }
-#pragma unroll
-        for (int ps = 0; ps < WP; ++ps) {
-            // BK = 64 over a Kpad that is only a multiple of 32: the k >= Kpad half (kq4 >= 32 of
-            // the last tile) re-reads the first half, 128 bytes back (finite values; the matching
-            // X columns are zero) instead of running past the row / the buffer
-            const int koff = (BK <= 32 || l_k0 + kq4 < p.Kpad) ? l_k0 * 4 : -128;
-            if (GEMM1X1 && (SSD_CONV_ABLATE & 256)) {
-                const int u = tid + ps * 256;
-                const int n = n0 + u / UPR;
-                wr[ps] = f32x4{0.f, 0.f, 0.f, 0.f};
-                if (u < WU && n < p.Npad && l_k0 + kq4 < p.Kpad)
-                    wr[ps] = *reinterpret_cast<const f32x4*>(p.w + (long)n * p.Kpad + l_k0 + kq4);
-            } else
-            wr[ps] = *reinterpret_cast<const f32x4*>(wbase + (unsigned)(woff[ps] + koff));
-        }
-    };
-    // swizzled float column of this thread's 16-byte unit; the swizzle key of a row is the same in
-    // every 256-thread pass (a pass advances the row by 256 / UPR, a multiple of the key's period)
-    const int st_row0 = tid / UPR;
-    const int st_col = SWZ ? ((((kq4 >> 2) ^ (BK == 32 ? (st_row0 >> 1) & 7 : st_row0 & 15)) << 2)) : kq4;
-    auto store_tile = [&](int stage) {
-        if (SSD_CONV_ABLATE & 2) return;
-        float* Xs = smem + stage * (BM + BN) * LDK;
-        float* Ws = Xs + BM * LDK;
-#pragma unroll
-        for (int ps = 0; ps < XP; ++ps) {
-            const int u = tid + ps * 256;
-            if (XU % 256 == 0 || u < XU)
-                *reinterpret_cast<f32x4*>(Xs + (u / UPR) * LDK + st_col) =
-                    (GEMM1X1 || x_is_valid(ps)) ? xr[ps] : f32x4{0.f, 0.f, 0.f, 0.f};
-        }
-#pragma unroll
-        for (int ps = 0; ps < WP; ++ps) {
-            const int u = tid + ps * 256;
-            if (WU % 256 == 0 || u < WU) *reinterpret_cast<f32x4*>(Ws + (u / UPR) * LDK + st_col) = wr[ps];
-        }
-
-    };
-
-    f32x4 acc[MT][NT];
-#pragma unroll
-    for (int mi = 0; mi < MT; ++mi)
-#pragma unroll
-        for (int ni = 0; ni < NT; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-    const int frow = lane & 15, fk = (lane >> 4) * 4;
-    // fragment column (floats) per 16-wide k unit: tile rows are multiples of 16, so the swizzle
-    // key only depends on frow
-    int fcol[BK / 16];
-#pragma unroll
-    for (int kc = 0; kc < BK / 16; ++kc)
-        fcol[kc] = SWZ ? (((kc * 4 + (lane >> 4)) ^ (BK == 32 ? (frow >> 1) & 7 : frow)) << 2) : kc * 16 + fk;
-    if (kt_begin < kt_end) {
-        tile_setup(kt_begin);
-        load_tile();
-        store_tile(0);
-    }
-    __syncthreads();
-    for (int kt = kt_begin; kt < kt_end; ++kt) {
-        const int stage = (kt - kt_begin) & 1;
-        const float* Xs = smem + stage * (BM + BN) * LDK;
-        const float* Ws = Xs + BM * LDK;
-        const bool more = kt + 1 < kt_end;
-        if (more) {
-            tile_advance();
-            load_tile();
-        }
-#pragma unroll
-        for (int kc = 0; kc < ((SSD_CONV_ABLATE & 4) ? 0 : BK / 16); ++kc) {
-            f32x4 a[NT], b[MT];
-#pragma unroll
-            for (int ni = 0; ni < NT; ++ni)
-                a[ni] = *reinterpret_cast<const f32x4*>(Ws + ((wn * NT + ni) * 16 + frow) * LDK + fcol[kc]);
-#pragma unroll
-            for (int mi = 0; mi < MT; ++mi)
-                b[mi] = *reinterpret_cast<const f32x4*>(Xs + ((wm * MT + mi) * 16 + frow) * LDK + fcol[kc]);
-            if (SSD_CONV_ABLATE & 16) {
-#pragma unroll
-                for (int ni = 0; ni < NT; ++ni) asm volatile("" ::"v"(a[ni]));
-#pragma unroll
-                for (int mi = 0; mi < MT; ++mi) asm volatile("" ::"v"(b[mi]));
-                continue;
-            }
-#pragma unroll
-            for (int s = 0; s < 4; ++s)
-#pragma unroll
-                for (int mi = 0; mi < MT; ++mi)
-#pragma unroll
-                    for (int ni = 0; ni < NT; ++ni)
-                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[ni][s], b[mi][s], acc[mi][ni], 0, 0, 0);
-        }
-        if (more) store_tile(stage ^ 1);
-        if (SSD_CONV_ABLATE & 64) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // LDS-only barrier
-        else if (!(SSD_CONV_ABLATE & 8)) __syncthreads();
-    }
-
-    // ---- epilogue: lane holds out[m = .. + (lane & 15)][n = .. + (lane >> 4) * 4 + 0..3]
-    // (M < 2^31 is checked on the host: 32-bit index arithmetic)
-    if (p.split_k > 1) {           // partial sums only; scale/shift/act/residual happen in the reduce
-#pragma unroll
-        for (int mi = 0; mi < MT; ++mi) {
-            const int m = (int)m0 + (wm * MT + mi) * 16 + (lane & 15);
-            if (m >= (int)p.M) continue;
-#pragma unroll
-            for (int ni = 0; ni < NT; ++ni) {
-                const int n = n0 + (wn * NT + ni) * 16 + (lane >> 4) * 4;
-                if (n >= p.Cout) continue;
-                float* prow = p.partial + ((long)blockIdx.y * p.M + m) * p.Cout + n;
-                if (n + 3 < p.Cout && (p.Cout & 3) == 0) {
-                    *reinterpret_cast<f32x4*>(prow) = acc[mi][ni];
-                } else {
-                    for (int j = 0; j < 4; ++j)
-                        if (n + j < p.Cout) prow[j] = acc[mi][ni][j];
-                }
-            }
-        }
-        return;
-    }
-    // All loads of the epilogue are issued first (scale/shift per column group, residual per
-    // tile), the stores follow back to back: a load between two stores costs a full store
-    // round trip on gfx950 (vmcnt counts stores and the waits are not selective).
-    f32x4 sc[NT], sh[NT];
-    bool vecn[NT];
-#pragma unroll
-    for (int ni = 0; ni < NT; ++ni) {
-        const int n = n0 + (wn * NT + ni) * 16 + (lane >> 4) * 4;
-        const bool straddle = p.n_split && n < p.n_split && n + 3 >= p.n_split;
-        vecn[ni] = (n + 3 < p.Cout) && !straddle;
-        sc[ni] = f32x4{1.f, 1.f, 1.f, 1.f};
-        sh[ni] = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (vecn[ni]) {
-            if (p.scale) sc[ni] = *reinterpret_cast<const f32x4*>(p.scale + n);
-            if (p.shift) sh[ni] = *reinterpret_cast<const f32x4*>(p.shift + n);
-        }
-    }
-    const bool res_vec = p.residual && (p.Cout & 3) == 0;
-    f32x4 rs[MT][NT];
-    if (res_vec) {
-#pragma unroll
-        for (int mi = 0; mi < MT; ++mi) {
-            const int m = (int)m0 + (wm * MT + mi) * 16 + (lane & 15);
-#pragma unroll
-            for (int ni = 0; ni < NT; ++ni) {
-                const int n = n0 + (wn * NT + ni) * 16 + (lane >> 4) * 4;
-                rs[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
-                if (m < (int)p.M && vecn[ni]) rs[mi][ni] = *reinterpret_cast<const f32x4*>(p.residual + (long)m * p.Cout + n);
-            }
-        }
-    }
-#pragma unroll
-    for (int mi = 0; mi < MT; ++mi) {
-        const int m = (int)m0 + (wm * MT + mi) * 16 + (lane & 15);
-        if (m >= (int)p.M) continue;
-        const int b = m / HoWo;
-        const int pix = m - b * HoWo;
-        float* orow = p.out + (long)b * p.out_batch_stride + (long)pix * p.out_pixel_stride;
-        float* orow2 = p.n_split ? p.out2 + (long)b * p.out2_batch_stride + (long)pix * p.out2_pixel_stride - p.n_split : nullptr;
-#pragma unroll
-        for (int ni = 0; ni < NT; ++ni) {
-            const int n = n0 + (wn * NT + ni) * 16 + (lane >> 4) * 4;
-            if (n >= p.Cout) continue;
-            f32x4 v = acc[mi][ni];
-            if (vecn[ni]) {
-                v = v * sc[ni] + sh[ni];
-#pragma unroll
-                for (int j = 0; j < 4; ++j) v[j] = apply_act(v[j], p.act);
-                if (res_vec) {
-                    v = v + rs[mi][ni];
-                } else if (p.residual) {
-                    const float* rr = p.residual + (long)m * p.Cout + n;
-                    for (int j = 0; j < 4; ++j) v[j] += rr[j];
-                }
-                const bool side2 = p.n_split && n >= p.n_split;
-                float* dst = (side2 ? orow2 : orow) + n;
-                if ((side2 ? p.vec_store2 : p.vec_store) && ((((uintptr_t)dst) & 15) == 0)) {
-                    *reinterpret_cast<f32x4*>(dst) = v;
-                } else {
-                    dst[0] = v[0]; dst[1] = v[1]; dst[2] = v[2]; dst[3] = v[3];
-                }
-            } else {
-                for (int j = 0; j < 4; ++j) {
-                    if (n + j >= p.Cout) break;
-                    float t = v[j];
-                    if (p.scale) t = t * p.scale[n + j];
-                    if (p.shift) t = t + p.shift[n + j];
-                    t = apply_act(t, p.act);
-                    if (p.residual) t += p.residual[(long)m * p.Cout + n + j];
-                    float* drow = (p.n_split && n + j >= p.n_split) ? orow2 : orow;
-                    drow[n + j] = t;
-                }
-            }
-        }
-    }
-}
+// conv_mfma_kernel: ssd_conv_mfma.h
 
 // Split-K reduction + epilogue (deterministic order: s = 0, 1, ...).  A thread sums 4
 // consecutive flat [M*Cout] elements with float4 loads (slabs are 16-byte aligned when
@@ -618,16 +280,20 @@ constexpr int kNumMfmaCfgs = sizeof(kCfgs) / sizeof(kCfgs[0]);
 // config ids: [0, kNumMfmaCfgs) implicit-GEMM tiles, then the Winograd F(2x2,3x3) tiles
 // (csrc/ssd_wino.hip), last = VALU direct kernel
 // then the skinny (in-workgroup K split) tiles (csrc/ssd_skinny.hip)
+// then the split-bf16 implicit-GEMM tiles (csrc/ssd_conv3.hip)
 static int skinny_cfg0() { return kNumMfmaCfgs + wino_num_configs(); }
-static int direct_cfg() { return kNumMfmaCfgs + wino_num_configs() + skinny_num_configs(); }
+static int mfma3_cfg0() { return kNumMfmaCfgs + wino_num_configs() + skinny_num_configs(); }
+static int direct_cfg() { return kNumMfmaCfgs + wino_num_configs() + skinny_num_configs() + mfma3_num_configs(); }
 #define kSkinnyCfg0 skinny_cfg0()
+#define kMfma3Cfg0 mfma3_cfg0()
 #define kDirectCfg direct_cfg()
 
 int conv_num_mfma_configs() { return kNumMfmaCfgs; }
-int conv_num_configs() { return kNumMfmaCfgs + wino_num_configs() + skinny_num_configs() + 1; }
+int conv_num_configs() { return kDirectCfg + 1; }
 const char* conv_config_name(int cfg) {
     if (cfg == kDirectCfg) return "direct_valu";
-    if (cfg >= kSkinnyCfg0 && cfg < kDirectCfg) return skinny_config_name(cfg - kSkinnyCfg0);
+    if (cfg >= kMfma3Cfg0 && cfg < kDirectCfg) return mfma3_config_name(cfg - kMfma3Cfg0);
+    if (cfg >= kSkinnyCfg0 && cfg < kMfma3Cfg0) return skinny_config_name(cfg - kSkinnyCfg0);
     if (cfg >= kNumMfmaCfgs && cfg < kSkinnyCfg0) return wino_config_name(cfg - kNumMfmaCfgs);
     if (cfg < 0 || cfg >= kNumMfmaCfgs) return "?";
     return kCfgs[cfg].name;
@@ -639,7 +305,8 @@ static bool is_gemm1x1(const ConvParams& p) {
 
 bool conv_config_valid(int cfg, const ConvParams& p) {
     if (cfg == kDirectCfg) return (size_t)p.K * ((p.Cout + 3) & ~3) * 4 <= 64 * 1024;
-    if (cfg >= kSkinnyCfg0 && cfg < kDirectCfg) return skinny_config_valid(cfg - kSkinnyCfg0, p);
+    if (cfg >= kMfma3Cfg0 && cfg < kDirectCfg) return mfma3_config_valid(cfg - kMfma3Cfg0, p);
+    if (cfg >= kSkinnyCfg0 && cfg < kMfma3Cfg0) return skinny_config_valid(cfg - kSkinnyCfg0, p);
     if (cfg >= kNumMfmaCfgs && cfg < kSkinnyCfg0) return wino_config_valid(cfg - kNumMfmaCfgs, p);
     if (cfg < 0 || cfg >= kNumMfmaCfgs) return false;
     if (((uintptr_t)p.in & 15) || ((uintptr_t)p.w & 15)) return false;
@@ -673,14 +340,16 @@ int conv_pick_config(const ConvParams& p) {
 }
 
 long conv_grid_blocks(int cfg, const ConvParams& p) {
-    if (cfg >= kSkinnyCfg0 && cfg < kDirectCfg) return skinny_grid_blocks(cfg - kSkinnyCfg0, p);
+    if (cfg >= kMfma3Cfg0 && cfg < kDirectCfg) return mfma3_grid_blocks(cfg - kMfma3Cfg0, p);
+    if (cfg >= kSkinnyCfg0 && cfg < kMfma3Cfg0) return skinny_grid_blocks(cfg - kSkinnyCfg0, p);
     if (cfg >= kNumMfmaCfgs && cfg < kSkinnyCfg0) return wino_grid_blocks(cfg - kNumMfmaCfgs, p);
     if (cfg < 0 || cfg >= kNumMfmaCfgs) return 0;
     const ConvCfg& g = kCfgs[cfg];
     return ((p.M + g.BM - 1) / g.BM) * ((p.Cout + g.BN - 1) / g.BN);
 }
 int conv_k_tiles(int cfg, const ConvParams& p) {
-    if (cfg >= kSkinnyCfg0 && cfg < kDirectCfg) return p.K / 16;
+    if (cfg >= kMfma3Cfg0 && cfg < kDirectCfg) return mfma3_k_tiles(p);
+    if (cfg >= kSkinnyCfg0 && cfg < kMfma3Cfg0) return p.K / 16;
     if (cfg >= kNumMfmaCfgs && cfg < kSkinnyCfg0) return wino_k_tiles(p);
     if (cfg < 0 || cfg >= kNumMfmaCfgs) return 0;
     return (p.K + kCfgs[cfg].BK - 1) / kCfgs[cfg].BK;
@@ -697,7 +366,12 @@ int conv_launch(const ConvParams& p, int cfg, hipStream_t st) {
                   p.Cin, p.kh, p.kw, p.stride);
         return SSD_E_UNSUPPORTED;
     }
-    if (cfg >= kSkinnyCfg0 && cfg < kDirectCfg) return skinny_launch(p, cfg - kSkinnyCfg0, st);
+    if (cfg >= kMfma3Cfg0 && cfg < kDirectCfg) {
+        const int rc = mfma3_launch(p, cfg - kMfma3Cfg0, st);
+        if (rc || p.split_k <= 1) return rc;
+        return launch_splitk_reduce(p, st);
+    }
+    if (cfg >= kSkinnyCfg0 && cfg < kMfma3Cfg0) return skinny_launch(p, cfg - kSkinnyCfg0, st);
     if (cfg >= kNumMfmaCfgs && cfg < kSkinnyCfg0) {
         const int rc = wino_launch(p, cfg - kNumMfmaCfgs, st);
         if (rc || p.split_k <= 1) return rc;
@@ -802,7 +476,7 @@ int ssd_conv_out_size(int in, int k, int stride, int dilation, int pad_before, i
 
 size_t ssd_conv_packed_weight_floats(int kh, int kw, int Cin, int Cout) {
     if (kh < 1 || kw < 1 || Cin < 1 || Cout < 1) return 0;
-    return (size_t)conv_kpad(kh * kw * Cin) * conv_npad(Cout);
+    return conv_packed_floats(kh * kw * Cin, Cout);
 }
 
 int ssd_conv_pack_weights(const float* hwio_dev, int kh, int kw, int Cin, int Cout, float* packed_dev,
@@ -810,7 +484,9 @@ int ssd_conv_pack_weights(const float* hwio_dev, int kh, int kw, int Cin, int Co
     SSD_CHECK_ARG(hwio_dev && packed_dev, "ssd_conv_pack_weights: NULL pointer");
     SSD_CHECK_ARG(kh >= 1 && kw >= 1 && Cin >= 1 && Cout >= 1, "ssd_conv_pack_weights: bad shape");
     const int K = kh * kw * Cin;
-    return launch_pack_weights(hwio_dev, K, Cout, conv_kpad(K), conv_npad(Cout), packed_dev, (hipStream_t)stream);
+    int rc = launch_pack_weights(hwio_dev, K, Cout, conv_kpad(K), conv_npad(Cout), packed_dev, (hipStream_t)stream);
+    if (!rc) rc = launch_pack_split(packed_dev, K, Cout, (hipStream_t)stream);
+    return rc;
 }
 
 int ssd_conv_num_configs(void) { return conv_num_configs(); }
@@ -827,6 +503,7 @@ int ssd_conv2d_ex(const ssd_conv_desc* d, const float* in_dev, const float* pack
     SSD_CHECK_ARG(in_dev && packed_w_dev && out_dev, "conv2d: NULL pointer");
     SSD_CHECK_ARG(!d->has_residual || residual_dev, "conv2d: has_residual set but residual is NULL");
     p.in = in_dev; p.w = packed_w_dev; p.scale = scale_dev; p.shift = shift_dev;
+    p.w3 = conv_split_planes(packed_w_dev, p.K, p.Cout);
     p.residual = d->has_residual ? residual_dev : nullptr;
     p.out = out_dev;
     p.out_pixel_stride = out_pixel_stride > 0 ? out_pixel_stride : p.Cout;

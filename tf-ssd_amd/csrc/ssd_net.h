@@ -64,6 +64,7 @@ struct Layer {
     float* splitk_part = nullptr;   // this layer's own split-K slab (layers may run concurrently)
     // LK_FUSED: weight copies with the folded BatchNorm scale multiplied in (per output channel)
     float *fz_we = nullptr, *fz_wd = nullptr, *fz_wp = nullptr;
+    float *fz_we3 = nullptr, *fz_wp3 = nullptr;      // bf16 planes of fz_we / fz_wp for the split-bf16 band kernel (ssd_band3.hip)
     int side = 0;                   // 1, 2: runs on that side stream (SSD head convs)
     hipEvent_t ev_ready = nullptr;  // recorded on the main stream when this layer's OUTPUT is complete
 };
@@ -85,7 +86,7 @@ struct ssd_net {
     bool fuse_blocks = true;        // run eligible inverted-residual blocks as one fused kernel
     bool fuse_dwproj = true;        // ... and depthwise + project of the others as one kernel
     bool use_wino = true;           // offer the Winograd F(2x2,3x3) kernels to the autotune
-    bool fuse_band = true;          // row-band kernel (ssd_bandblock.hip) for blocks 1-6 instead of the 8x8-tile kernel
+    int fuse_band = 2;              // blocks 1-6: 2 row-band kernel with the 1x1 convs on the bf16 matrix cores through an exact 3-way split (ssd_band3.hip), 1 row-band kernel on the fp32 MFMA (ssd_bandblock.hip), 0 the 8x8-tile kernel
     int fuse_image = 1;             // whole-image block kernel (ssd_imgblock.hip): 0 never, 1 where it won the finalize-time race, 2 wherever it applies
     int tail_prio = 0;              // 1: extras tail on side[2] (highest priority); 2: its small heads too
     bool tail_on_side = false;      // diagnostics: big heads on the main stream, extras tail + small heads on the side streams

@@ -305,6 +305,7 @@ static ConvParams layer_conv_params(const ssd_net& net, const Layer& l, int B, c
     ConvParams p{};
     p.in = in;
     p.w = l.packed;
+    p.w3 = conv_split_planes(l.packed, l.kh * l.kw * l.Cin, l.Cout);
     p.wino_w = l.wino;
     p.scale = l.scale;
     p.shift = l.shift;
@@ -354,6 +355,8 @@ static FusedBlockParams fused_params(const ssd_net& net, const Layer& f, int B) 
     p.kpad_p = conv_kpad(lp.Cin);
     p.npad_p = conv_npad(lp.Cout);
     p.e_out = f.e_out >= 0 ? net.tensors[f.e_out].dev : nullptr;
+    p.we3 = reinterpret_cast<const short*>(f.fz_we3);
+    p.wp3 = reinterpret_cast<const short*>(f.fz_wp3);
     if (!fused_block_supported(p) && image_block_supported(p)) {
         p.groups = net.img_slabs ? image_block_groups(p, B) : 1;
         p.slabs = net.img_slabs;
@@ -434,7 +437,10 @@ static int run_layer_impl(ssd_net& net, const Layer& l, int B, float* deltas_out
             {
                 const FusedBlockParams p = fused_params(net, l, B);
                 if (fused_block_supported(p))       // blocks 1-6: row-band kernel where it applies, else the 8x8-tile kernel
+{
+                    if (net.fuse_band == 2 && p.we3 && band3_block_supported(p)) return launch_band3_block(p, st);
                     return net.fuse_band && band_block_supported(p) ? launch_band_block(p, st) : launch_fused_block(p, st);
+                }
                 return launch_image_block(p, st);
             }
     }
@@ -820,7 +826,7 @@ int ssd_net_finalize(ssd_net* net, int max_batch) {
         l.splitk_part = nullptr;        // autotune runs on the shared slab; per-layer slabs are re-planned below
         if (l.kind == LK_CONV) {
             const int K = l.kh * l.kw * l.Cin;
-            int rc = dev_alloc(*net, (size_t)conv_kpad(K) * conv_npad(l.Cout), &l.packed);
+            int rc = dev_alloc(*net, conv_packed_floats(K, l.Cout), &l.packed);
             if (rc) return rc;
             if (l.p_kernel2 < 0) {
                 rc = launch_pack_weights(net->params[l.p_kernel].dev, K, l.Cout, conv_kpad(K), conv_npad(l.Cout),
@@ -832,6 +838,7 @@ int ssd_net_finalize(ssd_net* net, int max_batch) {
                     rc = launch_pack_weights(net->params[l.p_kernel2].dev, K, l.Cout - l.Cout1, conv_kpad(K),
                                              l.Cout - l.Cout1, l.packed + (size_t)l.Cout1 * conv_kpad(K), st);
             }
+            if (!rc) rc = launch_pack_split(l.packed, K, l.Cout, st);
             if (rc) return rc;
             // Winograd form of the 3x3 stride-1 convs (heads, VGG16 backbone): the autotune decides
             if (l.kh == 3 && l.kw == 3 && l.stride == 1 && l.dil == 1 && l.Cin % 16 == 0 && l.res < 0 && net->use_wino) {
@@ -897,6 +904,15 @@ int ssd_net_finalize(ssd_net* net, int max_batch) {
         if (!rc) rc = launch_scale_cols(net->params[ld.p_kernel].dev, ld.scale, 9, ld.Cout, f.fz_wd, st);
         if (!rc) rc = launch_scale_rows(lp.packed, lp.scale, conv_npad(lp.Cout), lp.Cout, conv_kpad(lp.Cin), f.fz_wp, st);
         if (rc) return rc;
+        // split-bf16 band kernel: the same two matrices as three bf16 planes each (exact split, see ssd_band3.hip)
+        f.fz_we3 = f.fz_wp3 = nullptr;
+        if (band3_block_supported(fused_params(*net, f, 1))) {
+            rc = dev_alloc(*net, (band3_we_shorts(le.Cout) + 1) / 2, &f.fz_we3);
+            if (!rc) rc = dev_alloc(*net, (band3_wp_shorts(conv_npad(lp.Cout), le.Cout) + 1) / 2, &f.fz_wp3);
+            if (!rc) rc = launch_band3_pack(f.fz_we, le.Cout, le.Cin, conv_kpad(le.Cin), reinterpret_cast<short*>(f.fz_we3), f.fz_wp,
+                                            conv_npad(lp.Cout), conv_kpad(lp.Cin), reinterpret_cast<short*>(f.fz_wp3), st);
+            if (rc) return rc;
+        }
     }
     // whole-image block kernel: slab workspace for the largest (groups x batch) product any batch
     // up to max_batch can ask for, and the arrival tickets (zero between launches)
@@ -1328,7 +1344,7 @@ int ssd_net_profile_fused(ssd_net* net, const char* layer, int B, double* cycles
     FusedBlockParams p = fused_params(*net, *f, B);
     const bool image = !fused_block_supported(p) && image_block_supported(p);
     SSD_CHECK_ARG(fused_block_supported(p) || image, "ssd_net_profile_fused: layer not supported by the fused kernels");
-    const bool band = !image && net->fuse_band && band_block_supported(p);
+    const bool band = !image && net->fuse_band == 1 && band_block_supported(p);
     auto launch = [&](const FusedBlockParams& q) {
         return image ? launch_image_block(q, nullptr) : band ? launch_band_block(q, nullptr) : launch_fused_block(q, nullptr);
     };
@@ -1378,8 +1394,8 @@ int ssd_net_set_option(ssd_net* net, const char* name, int value) {
         net->drop_graphs();
         return SSD_OK;
     }
-    if (std::string(name) == "fuse_band") {      // row-band kernel for blocks 1-6 (default 1; 0: the 8x8-tile kernel)
-        net->fuse_band = value != 0;
+    if (std::string(name) == "fuse_band") {      // blocks 1-6: 2 (default) split-bf16 row-band kernel, 1 fp32-MFMA row-band kernel, 0 the 8x8-tile kernel
+        net->fuse_band = value < 0 ? 0 : (value > 2 ? 2 : value);
         net->drop_graphs();
         return SSD_OK;
     }
