@@ -149,6 +149,7 @@ const char* mfma3_config_name(int i);
 bool mfma3_config_valid(int i, const ConvParams& p);
 long mfma3_grid_blocks(int i, const ConvParams& p);
 int mfma3_k_tiles(const ConvParams& p);
+void mfma3_tile(int i, int* BM, int* BN);
 int mfma3_launch(const ConvParams& p, int i, hipStream_t st);
 
 int launch_dwconv3x3(const float* in, int B, int H, int W, int C, int stride, int pad_t, int pad_l,

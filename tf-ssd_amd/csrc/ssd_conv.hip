@@ -335,6 +335,23 @@ int conv_pick_config(const ConvParams& p) {
         const double cost = (t_mfma > t_mem ? t_mfma : t_mem) + 0.25 * (t_mfma < t_mem ? t_mfma : t_mem);
         if (cost < best_cost) { best_cost = cost; best = c; }
     }
+    // split-bf16 tiles (need the weights' planes): matrix rate derated to what the kernels measured (the staging of
+    // the split operands shares the loop), 6 bytes per weight element; not for the smallest problems
+    if (p.w3 && p.M >= 2048 && p.K >= 64) {
+        for (int c = 0; c < mfma3_num_configs(); ++c) {
+            if (!mfma3_config_valid(c, p)) continue;
+            int BM, BN;
+            mfma3_tile(c, &BM, &BN);
+            const double mb = (double)((p.M + BM - 1) / BM), nb = (double)((p.Cout + BN - 1) / BN);
+            const double kk = (double)round_up(p.K, 32);
+            const double waves = ceil(mb * nb / 256.0);
+            const double t_mfma = waves * (double)BM * BN * kk * 2.0 / (260e12 / 256.0);
+            const double bytes = mb * BM * kk * nb * 4.0 + nb * BN * kk * mb * 6.0 + (double)p.M * p.Cout * 4.0;
+            const double t_mem = bytes / 6.0e12;
+            const double cost = (t_mfma > t_mem ? t_mfma : t_mem) + 0.25 * (t_mfma < t_mem ? t_mfma : t_mem);
+            if (cost < best_cost) { best_cost = cost; best = kMfma3Cfg0 + c; }
+        }
+    }
     if (best < 0 && conv_config_valid(kDirectCfg, p)) best = kDirectCfg;
     return best;
 }

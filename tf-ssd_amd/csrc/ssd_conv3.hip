@@ -76,6 +76,10 @@ long mfma3_grid_blocks(int i, const ConvParams& p) {
     return ((p.M + kCfg3[i].BM - 1) / kCfg3[i].BM) * ((p.Cout + kCfg3[i].BN - 1) / kCfg3[i].BN);
 }
 int mfma3_k_tiles(const ConvParams& p) { return (p.K + 31) / 32; }
+void mfma3_tile(int i, int* BM, int* BN) {
+    *BM = (i >= 0 && i < kNumCfg3) ? kCfg3[i].BM : 0;
+    *BN = (i >= 0 && i < kNumCfg3) ? kCfg3[i].BN : 0;
+}
 
 // the kernel only (the caller adds the split-K reduction)
 int mfma3_launch(const ConvParams& p, int i, hipStream_t st) {

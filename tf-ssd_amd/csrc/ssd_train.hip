@@ -153,6 +153,14 @@ __global__ __launch_bounds__(256) void pack_jobs_kernel(const PackJob* __restric
             }
         }
         j.dst[e] = v;
+        // the same matrix split into its three bf16 planes behind the fp32 one (split-bf16 conv tiles, ssd_conv3.hip)
+        short* pl = reinterpret_cast<short*>(j.dst + total);
+        const unsigned hb = __float_as_uint(v) & 0xffff0000u;
+        const float r1 = v - __uint_as_float(hb);
+        const unsigned mb = __float_as_uint(r1) & 0xffff0000u;
+        pl[e] = (short)(hb >> 16);
+        pl[total + e] = (short)(mb >> 16);
+        pl[2 * total + e] = (short)(__float_as_uint(r1 - __uint_as_float(mb)) >> 16);
     }
 }
 
@@ -1155,11 +1163,11 @@ int ssd_net_train_begin(ssd_net* net, int batch) {
         }
         if (l.kind == LK_CONV) {
             const int K = l.kh * l.kw * l.Cin;
-            if (!rc) rc = talloc(*s, (size_t)conv_kpad(K) * conv_npad(l.Cout), &t.wfwd);
+            if (!rc) rc = talloc(*s, conv_packed_floats(K, l.Cout), &t.wfwd);
             t.cpad = l.head_kind ? round_up(l.Cout, 32) : l.Cout;
             if (l.in != 0) {        // the image needs no gradient
                 const int Kb = l.kh * l.kw * t.cpad;
-                if (!rc) rc = talloc(*s, (size_t)conv_kpad(Kb) * conv_npad(l.Cin), &t.wbwd);
+                if (!rc) rc = talloc(*s, conv_packed_floats(Kb, l.Cin), &t.wbwd);
                 max_w = std::max(max_w, (size_t)l.kh * l.kw * t.cpad * l.Cin);
             }
             size_t dy = (size_t)batch * l.Ho * l.Wo * t.cpad;
@@ -1301,6 +1309,7 @@ int ssd_net_train_forward_backward(ssd_net* net, const float* image_dev, int B, 
             ConvParams p = dense_conv_params(B, l.H, l.W, l.Cin, l.Cout, l.kh, l.kw, l.stride, l.dil, l.pt, l.pl, l.Ho, l.Wo);
             p.in = x;
             p.w = t.wfwd;
+            p.w3 = conv_split_planes(t.wfwd, l.kh * l.kw * l.Cin, l.Cout);
             if (l.p_bn >= 0) {
                 p.out = t.pre;
                 p.act = SSD_ACT_NONE;
@@ -1529,6 +1538,7 @@ int ssd_net_train_forward_backward(ssd_net* net, const float* image_dev, int B, 
         ConvParams p = dense_conv_params(B, Hg, Wg, ldy, l.Cin, kh, kw, 1, d, pt, pl, l.H, l.W);
         p.in = gin;
         p.w = t.wbwd;
+        p.w3 = conv_split_planes(t.wbwd, p.K, p.Cout);
         p.out = s.gact[l.in];
         p.act = SSD_ACT_NONE;
         p.residual = s.gwritten[l.in] ? s.gact[l.in] : nullptr;      // accumulate in the epilogue
