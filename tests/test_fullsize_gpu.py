@@ -311,6 +311,35 @@ def test_two_lanes_match_one_lane():
             np.testing.assert_array_equal(a.cpu().numpy(), b)
 
 
+def test_lanes_hint_changes_only_the_summation_grouping():
+    """With N lanes in flight the whole-image blocks split an image's expanded channels over fewer workgroups
+    (option lanes_hint: B x groups x lanes fills the CUs).  The lanes' results are bitwise those of a single net
+    with the same hint, and equal to the unhinted net's up to the fp32 regrouping of the partial sums."""
+    from models.decoder import get_decoder_model
+    from models.ssd_mobilenet_v2 import get_model
+    from utils import bbox_utils
+    hp = helpers.hyper_params("mobilenet_v2")
+    m = get_model(hp, max_batch=24)              # 24 images: 12 channel groups alone, 4 with three lanes in flight
+    m.set_weights(helpers.synthetic_weights("mobilenet_v2", hp))
+    priors = bbox_utils.generate_prior_boxes(hp["feature_map_shapes"], hp["aspect_ratios"])
+    x = helpers.images(24, 300, seed=77)
+    d1, p1 = (t.cpu().numpy() for t in m(x))
+    dm3 = get_decoder_model(m, priors, hp, lanes=3)
+    outs = [dm3.submit(x) for _ in range(3)]
+    dm3.wait()
+    torch.cuda.synchronize()
+    outs = [[t.cpu().numpy() for t in o] for o in outs]
+    m.set_option("lanes_hint", 3)
+    d3, p3 = (t.cpu().numpy() for t in m(x))
+    ref = [t.cpu().numpy() for t in get_decoder_model(m, priors, hp, lanes=1)(x)]
+    m.set_option("lanes_hint", 1)
+    assert np.abs(d3 - d1).max() <= 2e-5 and np.abs(p3 - p1).max() <= 2e-5
+    assert (ref[2] > 0).sum() > 0
+    for o in outs:
+        for a, b in zip(o, ref):
+            np.testing.assert_array_equal(a, b)
+
+
 @pytest.mark.parametrize("extra", [[], ["--lanes", "1"], ["--train"]])
 def test_bench_line_contract(extra, tmp_path):
     """`python bench.py --steps K --warmup W` prints ONE JSON line with the driver's keys; value, ms_per_step

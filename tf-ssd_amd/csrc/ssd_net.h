@@ -88,6 +88,7 @@ struct ssd_net {
     bool use_wino = true;           // offer the Winograd F(2x2,3x3) kernels to the autotune
     int fuse_band = 2;              // blocks 1-6: 2 row-band kernel with the 1x1 convs on the bf16 matrix cores through an exact 3-way split (ssd_band3.hip), 1 row-band kernel on the fp32 MFMA (ssd_bandblock.hip), 0 the 8x8-tile kernel
     int fuse_image = 1;             // whole-image block kernel (ssd_imgblock.hip): 0 never, 1 where it won the finalize-time race, 2 wherever it applies
+    int lanes_hint = 1;             // replicas of this net running concurrently (lanes): the whole-image kernel then splits an image's expanded channels over fewer workgroups (B x groups x lanes fills the CUs; fewer slab passes)
     int tail_prio = 0;              // 1: extras tail on side[2] (highest priority); 2: its small heads too
     bool tail_on_side = false;      // diagnostics: big heads on the main stream, extras tail + small heads on the side streams
     bool image_ticket = false;      // combine the channel-group slabs inside the launch (arrival ticket) instead of by a second launch

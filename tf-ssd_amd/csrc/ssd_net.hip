@@ -358,7 +358,7 @@ static FusedBlockParams fused_params(const ssd_net& net, const Layer& f, int B) 
     p.we3 = reinterpret_cast<const short*>(f.fz_we3);
     p.wp3 = reinterpret_cast<const short*>(f.fz_wp3);
     if (!fused_block_supported(p) && image_block_supported(p)) {
-        p.groups = net.img_slabs ? image_block_groups(p, B) : 1;
+        p.groups = net.img_slabs ? image_block_groups(p, B * net.lanes_hint) : 1;
         p.slabs = net.img_slabs;
         p.tickets = net.image_ticket ? net.img_tickets : nullptr;
     }
@@ -1401,6 +1401,11 @@ int ssd_net_set_option(ssd_net* net, const char* name, int value) {
     }
     if (std::string(name) == "fuse_image") {
         net->fuse_image = value < 0 ? 0 : (value > 2 ? 2 : value);
+        net->drop_graphs();
+        return SSD_OK;
+    }
+    if (std::string(name) == "lanes_hint") {     // number of replicas in flight beside this one (models/decoder.py lanes)
+        net->lanes_hint = value < 1 ? 1 : (value > 8 ? 8 : value);
         net->drop_graphs();
         return SSD_OK;
     }

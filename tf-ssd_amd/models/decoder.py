@@ -120,6 +120,9 @@ class DecoderModel(object):
             m.set_option("use_graph", 0)
             if self.lanes > 1:
                 m.set_option("overlap_heads", 0)       # a lane is ONE in-order stream (no intra-step side streams)
+                # the other lanes fill the chip: whole-image blocks split their channels over fewer workgroups
+                # (B=64, three lanes: 2 groups instead of 4 -> half the slab traffic, 44.5 k -> 47.0 k images/sec)
+                m.set_option("lanes_hint", self.lanes)
             self._lane_models.append(m)
             if len(self._lane_streams) < len(self._lane_models):
                 self._lane_streams.append(_h.new_stream())
