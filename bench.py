@@ -42,6 +42,15 @@ for _p in (REPO, os.path.join(REPO, "tf-ssd_amd")):
         sys.path.insert(0, _p)
 
 PEAK_FP32_MFMA_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md (v_mfma_f32_16x16x4_f32)
+# split-bf16 kernels (csrc/ssd_bf16x3.h): every fp32 product is SIX v_mfma_f32_16x16x32_bf16 products, so their
+# fp32-equivalent matrix peak is the dense bf16 peak (16 x the fp32 MFMA rate, same guide) / 6
+PEAK_BF16_MFMA_TFLOPS = 16 * PEAK_FP32_MFMA_TFLOPS
+PEAK_SPLIT_BF16_TFLOPS = PEAK_BF16_MFMA_TFLOPS / 6.0
+
+
+def matrix_peak(config):
+    """fp32-equivalent matrix-core peak of a conv kernel family (by config name)."""
+    return PEAK_SPLIT_BF16_TFLOPS if config.startswith("mfma3_") else PEAK_FP32_MFMA_TFLOPS
 
 
 def main():
@@ -191,7 +200,7 @@ def main():
     info, nfw = model.read_timing(B)
     model.set_timing(False)
     # the dense-conv family on the fp32 matrix cores: implicit-GEMM tiles and Winograd F(2x2,3x3) tiles
-    mfma = [r for r in info if r["kind"] == "conv" and r["config"].startswith(("mfma_", "wino_", "skinny_")) and r["flops"] > 0]
+    mfma = [r for r in info if r["kind"] == "conv" and r["config"].startswith(("mfma_", "mfma3_", "wino_", "skinny_")) and r["flops"] > 0]
     mfma_ms = sum(r["ms"] for r in mfma)
     mfma_flops = sum(r["flops"] for r in mfma)
     mfma_exec = sum(r["executed_flops"] for r in mfma)
@@ -204,11 +213,19 @@ def main():
         k = r["kind"]
         if k == "conv" and r["config"].startswith("wino_"):
             k = "conv_winograd"
+        elif k == "conv" and r["config"].startswith("mfma3_"):
+            k = "conv_split_bf16"
         elif k == "conv" and not r["config"].startswith(("mfma_", "skinny_")):
             k = "conv_direct"
         kinds[k] = kinds.get(k, 0.0) + r["ms"]
     achieved = mfma_flops / (mfma_ms * 1e-3) / 1e12 if mfma_ms > 0 else 0.0
     executed = mfma_exec / (mfma_ms * 1e-3) / 1e12 if mfma_ms > 0 else 0.0
+    # time the matrix cores would need at their peak (each layer against the peak of ITS instruction: fp32 MFMA, or
+    # six bf16 MFMAs per product) over the time the launches took: a fraction, never above 1
+    ideal_ms = sum(r["executed_flops"] / (matrix_peak(r["config"]) * 1e12) * 1e3 for r in mfma)
+    frac = ideal_ms / mfma_ms if mfma_ms > 0 else 0.0
+    peak_eff = executed / frac if frac > 0 else PEAK_FP32_MFMA_TFLOPS
+    split = [r for r in mfma if r["config"].startswith("mfma3_")]
     # the single most expensive launch of the family: what `rocprofv3 --kernel-trace --stats` of
     # `bench.py --no-overlap --no-other-leg` lists as that kernel's average duration (profiles/)
     dom = max(mfma, key=lambda r: r["ms"]) if mfma else None
@@ -231,7 +248,7 @@ def main():
     if os.path.exists(tpath) and hp["img_size"] == 300:
         try:
             fams = json.load(open(tpath))["families"]
-            fam_names = [k for k in ("conv_mfma_kernel", "conv_wino_kernel") if k in fams]
+            fam_names = [k for k in ("conv_mfma_kernel", "conv_mfma3_kernel", "conv_wino_kernel", "conv_skinny_kernel") if k in fams]
             nl = sum(fams[k]["FETCH_SIZE"]["launches"] for k in fam_names)
             # launch-weighted mean over the family's kernels (implicit-GEMM + Winograd tiles)
             fetch = 2.0 * 1024.0 * sum(fams[k]["FETCH_SIZE"]["KB_per_launch_reported"] * fams[k]["FETCH_SIZE"]["launches"]
@@ -278,17 +295,25 @@ def main():
                    # where the kernel choices came from (tuning.py): a shipped table = nothing timed on the
                    # device = the same kernels and bits in every process
                    "kernel_table": getattr(model, "tuning_info", None)},
-        "roofline": {"bound": "mfma", "kernel": "conv_mfma_kernel + conv_wino_kernel + conv_skinny_kernel (fp32 v_mfma_f32_16x16x4: implicit-GEMM, "
-                                                 "Winograd F(2x2,3x3) and in-workgroup-split-K tiles, all configs)",
+        "roofline": {"bound": "mfma", "kernel": "conv_mfma3_kernel (implicit-GEMM tiles, every fp32 product as six v_mfma_f32_16x16x32_bf16 of an exact "
+                                                 "3-way operand split) + conv_mfma_kernel / conv_wino_kernel / conv_skinny_kernel (fp32 v_mfma_f32_16x16x4: "
+                                                 "implicit-GEMM, Winograd F(2x2,3x3), in-workgroup-split-K tiles), all configs",
                      # `achieved` / `frac` count the FLOPs the matrix cores actually ISSUED (Winograd layers: 16
                      # multiplies per 2x2 output tile instead of 36, whole border tiles) over the hipEvent time of
                      # the family's launches on their stream: a fraction of the peak, never above 1.  The
                      # ALGORITHMIC figure (MACs x 2 of the direct convolution) is reported beside
                      # it as `achieved_algorithmic`; for Winograd layers it is an "effective" rate and may exceed
                      # the peak.
-                     "achieved": executed, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                     "frac": executed / PEAK_FP32_MFMA_TFLOPS, "frac_kind": "executed FLOPs / fp32 MFMA peak",
-                     "achieved_algorithmic": achieved, "frac_algorithmic": achieved / PEAK_FP32_MFMA_TFLOPS,
+                     # `peak` is the family's blended fp32-equivalent peak: each layer's executed FLOPs priced at the
+                     # peak of the instruction it runs on (fp32 MFMA 157.3; split-bf16 = dense bf16 2516.8 / 6 products
+                     # = 419.5), so that achieved / peak == frac == matrix time at peak / measured time.
+                     "achieved": executed, "peak": peak_eff, "unit": "TFLOP/s",
+                     "frac": frac, "frac_kind": "sum(executed FLOPs / peak of the layer's matrix instruction) / measured time",
+                     "peak_detail": {"fp32_mfma": PEAK_FP32_MFMA_TFLOPS, "bf16_mfma_dense": PEAK_BF16_MFMA_TFLOPS,
+                                     "split_bf16_fp32_equivalent": PEAK_SPLIT_BF16_TFLOPS,
+                                     "split_bf16_layers": len(split), "split_bf16_ms_per_step": sum(r["ms"] for r in split),
+                                     "split_bf16_executed_gflop_per_step": sum(r["executed_flops"] for r in split) / 1e9},
+                     "achieved_algorithmic": achieved, "frac_algorithmic_vs_fp32_mfma_peak": achieved / PEAK_FP32_MFMA_TFLOPS,
                      "winograd_layers": len(wino), "winograd_ms_per_step": sum(r["ms"] for r in wino),
                      "traffic": traffic, "traffic_detail": traffic_detail,
                      "launches_per_step": len(mfma), "kernel_ms_per_step": mfma_ms,
@@ -297,13 +322,15 @@ def main():
                          "layer": dom["name"], "config": dom["config"], "ms_per_launch": dom["ms"],
                          "algorithmic_gflop": dom["flops"] / 1e9, "executed_gflop": dom["executed_flops"] / 1e9,
                          "achieved": dom["executed_flops"] / (dom["ms"] * 1e-3) / 1e12,
-                         "frac": dom["executed_flops"] / (dom["ms"] * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS,
+                         "peak": matrix_peak(dom["config"]),
+                         "frac": dom["executed_flops"] / (dom["ms"] * 1e-3) / 1e12 / matrix_peak(dom["config"]),
                          "achieved_algorithmic": dom["flops"] / (dom["ms"] * 1e-3) / 1e12},
                      # the whole step (every kernel, incl. softmax/decode/NMS time) against the same peak, algorithmic FLOPs
-                     "achieved_step": step_tflops, "frac_step": step_tflops / PEAK_FP32_MFMA_TFLOPS,
+                     "achieved_step": step_tflops, "frac_step_vs_fp32_mfma_peak": step_tflops / PEAK_FP32_MFMA_TFLOPS,
                      "algorithmic_gflop_per_step_all": step_flops / 1e9},
         # the other half of the step: whole-block / depthwise+project / stem kernels (MFMA + VALU depthwise)
-        "roofline_fused": {"bound": "mfma", "kernel": "mbv2_stem_kernel + mbv2_band_block_kernel + mbv2_image_block_kernel + dwproj8_kernel (fused inverted-residual family)",
+        # (blocks 3-6 run the split-bf16 band kernel; the family is priced against the fp32 MFMA peak all the same)
+        "roofline_fused": {"bound": "mfma", "kernel": "mbv2_stem_kernel + mbv2_band_block_kernel + mbv2_band3_block_kernel + mbv2_image_block_kernel + dwproj8_kernel (fused inverted-residual family)",
                            "achieved": fused_flops / (fused_ms * 1e-3) / 1e12 if fused_ms > 0 else None,
                            "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
                            "frac": (fused_flops / (fused_ms * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS) if fused_ms > 0 else None,
@@ -380,7 +407,9 @@ def train_bench(args, hp, get_model, rank, world, dist):
                    "global_batch": world * B, "parallelism": "batch-DP x%d, RCCL all-reduce of %d fp32 gradients" % (
                        world, ssd_hip.lib().ssd_net_trainable_floats(model._net)),
                    "loss_first_step": first, "loss_last_step": last},
-        "roofline": {"bound": "mfma", "kernel": "training step (conv fwd + dgrad via conv_mfma_kernel, wgrad_mfma_kernel)",
+        # whole step against the fp32 MFMA peak (the convs the cost model hands to the split-bf16 tiles run above that
+        # rate; the step is bound by the elementwise / BatchNorm passes)
+        "roofline": {"bound": "mfma", "kernel": "training step (conv fwd + dgrad via conv_mfma_kernel / conv_mfma3_kernel, wgrad_mfma_kernel)",
                      "achieved": step_tflops, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
                      "frac": step_tflops / PEAK_FP32_MFMA_TFLOPS, "traffic": None,
                      "algorithmic_gflop_per_step": 3.0 * fwd_gflop},

@@ -363,10 +363,11 @@ def test_bench_line_contract(extra, tmp_path):
     assert abs(r["value"] - 8 / (r["ms_per_step"] * 1e-3)) <= 1e-6 * r["value"]
     if "--train" not in extra:
         ro = r["roofline"]
-        assert ro["bound"] == "mfma" and ro["unit"] == "TFLOP/s" and ro["peak"] == 157.3
+        assert ro["bound"] == "mfma" and ro["unit"] == "TFLOP/s" and ro["peak_detail"]["fp32_mfma"] == 157.3
         assert abs(ro["frac"] - ro["achieved"] / ro["peak"]) < 1e-9 and 0 < ro["frac"] < 1       # executed FLOPs: a real fraction
         assert ro["achieved_algorithmic"] >= ro["achieved"] * (1 - 1e-9) and "executed" in ro["frac_kind"]
-        assert ro["kernel_ms_per_step"] > 0 and 0 < ro["frac_step"] < 1
+        assert abs(ro["peak_detail"]["split_bf16_fp32_equivalent"] - 16 * 157.3 / 6) < 1e-9     # dense bf16 peak / six products
+        assert ro["kernel_ms_per_step"] > 0 and 0 < ro["frac_step_vs_fp32_mfma_peak"] < 1 and ro["peak_detail"]["fp32_mfma"] <= ro["peak"] <= ro["peak_detail"]["split_bf16_fp32_equivalent"] + 1e-9
         dk = ro["dominant_kernel"]
         assert dk["ms_per_launch"] > 0 and 0 < dk["frac"] < 1 and dk["ms_per_launch"] < r["ms_per_step"]
         # default: two batches in flight (one in-order stream / hardware queue per lane) are the headline, one step at
