@@ -10,12 +10,16 @@ from models.ssd_mobilenet_v2 import get_model
 from models.decoder import get_decoder_model
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 64
+S = int(sys.argv[2]) if len(sys.argv) > 2 else 300        # 512: the BASELINE configs[4] graph
 hp = dict(train_utils.get_hyper_params("mobilenet_v2")); hp["total_labels"] = 21
+if S == 512:
+    hp["img_size"] = 512
+    hp["feature_map_shapes"] = [32, 16, 8, 4, 2, 1]
 m = get_model(hp, max_batch=B)
 data_utils.synthetic_weights(m)
 pri = bbox_utils.generate_prior_boxes(hp["feature_map_shapes"], hp["aspect_ratios"])
 dm = get_decoder_model(m, pri, hp)
-x = h.to_dev(data_utils.synthetic_images(B))
+x = h.to_dev(data_utils.synthetic_images(B, S) if S != 300 else data_utils.synthetic_images(B))
 outs = {}
 for v in (0, 1, 2, 1, 2):
     m.set_option("fuse_band", v)

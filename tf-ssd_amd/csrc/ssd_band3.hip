@@ -244,6 +244,9 @@ const Band3Cfg kBand3[] = {
     B3CFG(24, 2, 7, 2, 2, 80),    // block 3
     B3CFG(32, 2, 4, 4, 1, 40),    // blocks 4-5
     B3CFG(32, 4, 4, 1, 2, 40),    // block 6
+    B3CFG(24, 2, 7, 2, 2, 136),   // the 512x512 graph: block 3 (128 -> 64), blocks 4-5 (64x64), block 6 (64 -> 32)
+    B3CFG(32, 2, 4, 4, 1, 72),
+    B3CFG(32, 4, 4, 1, 2, 72),
 };
 
 int band3_max_rows(const Band3Cfg& c, const FusedBlockParams& p) {

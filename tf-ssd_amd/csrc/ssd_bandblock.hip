@@ -281,6 +281,12 @@ const BandCfg kBand[] = {
     BCFG(24, 2, 7, 2, 2, 80),    // block 3: 24 -> 144 -> 32, 75x75 -> 38x38
     BCFG(32, 2, 4, 4, 1, 40),    // blocks 4-5: 32 -> 192 -> 32 (+x) at 38x38
     BCFG(32, 4, 4, 1, 2, 40),    // block 6: 32 -> 192 -> 64, 38x38 -> 19x19
+    // the 512x512 graph (BASELINE configs[4]): maps 128 / 64 wide.  (Block 1 at 256x256 stays on the 8x8-tile kernel: a full-width
+    // band holds ONE output row -- 3 input rows of pitch 264 fill the 9 tile slots -- and measured 127 us against 116.)
+    BCFG(24, 2, 8, 6, 1, 136),   // block 2 at 128x128
+    BCFG(24, 2, 7, 2, 2, 136),   // block 3: 128x128 -> 64x64
+    BCFG(32, 2, 4, 4, 1, 72),    // blocks 4-5 at 64x64
+    BCFG(32, 4, 4, 1, 2, 72),    // block 6: 64x64 -> 32x32
 };
 
 // largest band (output rows) a configuration can hold: input tiles and output tiles both have to fit
