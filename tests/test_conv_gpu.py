@@ -147,6 +147,38 @@ def test_conv2d_all_configs(case):
     assert ran >= 2
 
 
+def test_split_bf16_tiles_are_as_accurate_as_the_fp32_mfma():
+    """The `mfma3_*` tiles form every fp32 product from an exact three-way bf16 split of both operands (six bf16 MFMAs,
+    csrc/ssd_bf16x3.h).  On a long-K conv (K = 4608: VGG16 conv4 / the heads) their error against a float64 reference
+    stays within that of the fp32-MFMA tiles (both are fp32 roundings of the same sums), far inside the 1e-4 contract."""
+    import ssd_hip as h
+    lib = h.lib()
+    rng = np.random.default_rng(31)
+    B, H, Cin, Cout = 2, 19, 512, 128
+    x = rng.standard_normal((B, H, H, Cin)).astype(np.float32)
+    w = (rng.standard_normal((3, 3, Cin, Cout)) / np.sqrt(9 * Cin)).astype(np.float32)
+    xp = np.pad(x.astype(np.float64), ((0, 0), (1, 1), (1, 1), (0, 0)))
+    ref = np.zeros((B, H, H, Cout))
+    for ky in range(3):
+        for kx in range(3):
+            ref += xp[:, ky:ky + H, kx:kx + H, :] @ w[ky, kx].astype(np.float64)
+    errs = {"mfma_": [], "mfma3_": []}
+    for cfg in range(lib.ssd_conv_num_configs()):
+        name = lib.ssd_conv_config_name(cfg)
+        fam = b"mfma3_" if name.startswith(b"mfma3_") else (b"mfma_" if name.startswith(b"mfma_") else None)
+        if fam is None:
+            continue
+        rc, out = run_conv(x, w, None, None, None, 1, 1, (1, 1, 1, 1), cfg=cfg)
+        if rc == -3:
+            continue
+        assert rc == 0, lib.ssd_last_error()
+        errs[fam.decode()].append(float(np.abs(_np(out).astype(np.float64) - ref).max()))
+    assert len(errs["mfma3_"]) >= 8 and len(errs["mfma_"]) >= 8
+    print("max |err| vs float64: fp32 MFMA tiles %.2e, split-bf16 tiles %.2e (max |ref| %.2f)" % (
+        max(errs["mfma_"]), max(errs["mfma3_"]), float(np.abs(ref).max())))
+    assert max(errs["mfma3_"]) <= 1.5 * max(errs["mfma_"]) + 1e-7 and max(errs["mfma3_"]) <= 3e-5        # measured: 1.11e-5 (split-bf16) vs 1.19e-5 (fp32 MFMA)
+
+
 def test_conv2d_splitk_and_strided_output():
     rng = np.random.default_rng(5)
     B, H, Cin, Cout = 2, 10, 1280, 126
