@@ -17,12 +17,15 @@ SHAPES = [  # name, batch, H, Cin, Cout, k, stride, pads (t, b, l, r)
     ("mbv2 head2", B, 10, 1280, 150, 3, 1, (1, 1, 1, 1)), ("mbv2 head3", B, 5, 512, 150, 3, 1, (1, 1, 1, 1)),
     ("mbv2 head4", B, 3, 256, 150, 3, 1, (1, 1, 1, 1)), ("mbv2 extra1_1", B, 10, 1280, 256, 1, 1, (0, 0, 0, 0)),
     ("mbv2 extra1_2", B, 10, 256, 512, 3, 2, (0, 1, 0, 1)), ("mbv2 b13 expand", B, 19, 96, 576, 1, 1, (0, 0, 0, 0)),
+    ("vgg conv1_2", B // 2, 300, 64, 64, 3, 1, (1, 1, 1, 1)), ("vgg conv2_1", B // 2, 150, 64, 128, 3, 1, (1, 1, 1, 1)),
     ("vgg conv2_2", B // 2, 150, 128, 128, 3, 1, (1, 1, 1, 1)), ("vgg conv3_2", B // 2, 75, 256, 256, 3, 1, (1, 1, 1, 1)),
     ("vgg conv4_2", B // 2, 38, 512, 512, 3, 1, (1, 1, 1, 1)), ("vgg conv5_2", B // 2, 19, 512, 512, 3, 1, (1, 1, 1, 1)),
     ("vgg fc7", B // 2, 19, 1024, 1024, 1, 1, (0, 0, 0, 0)), ("vgg head1", B // 2, 38, 512, 100, 3, 1, (1, 1, 1, 1)),
 ]
 lib = h.lib()
 st = h.stream()
+if os.environ.get("ONLY"):
+    SHAPES = [s for s in SHAPES if os.environ["ONLY"] in s[0]]
 
 
 def family(name):
