@@ -69,6 +69,9 @@ def main():
     ap.add_argument("--no-overlap", action="store_true", help="profiling runs: no intra-step side streams (option overlap_heads 0), so per-kernel durations are uncontended")
     ap.add_argument("--layers", action="store_true", help="also print the per-layer table to stderr")
     ap.add_argument("--train", action="store_true", help="time the training step (SURVEY 8f N1) instead of inference")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="take the N > 1 code paths at world size 1: RCCL communicator alive (init, first collective, barriers, "
+                         "MAX-reduce of the time; --train: bucketed gradient all-reduce on the communication stream)")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -90,7 +93,16 @@ def main():
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     torch.cuda.set_device(local_rank)
     dist = None
-    if world > 1:
+    if args.force_dist:
+        os.environ["SSD_HIP_FORCE_DIST"] = "1"          # parallel.py: collectives also at world size 1
+        if world == 1:
+            import socket
+            with socket.socket() as sk:
+                sk.bind(("127.0.0.1", 0))
+                os.environ.setdefault("MASTER_PORT", str(sk.getsockname()[1]))
+            os.environ.setdefault("RANK", "0")
+            os.environ.setdefault("WORLD_SIZE", "1")
+    if world > 1 or args.force_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
@@ -294,7 +306,10 @@ def main():
                    "lane_calibration": getattr(decoder_model, "lane_calibration", None),
                    # where the kernel choices came from (tuning.py): a shipped table = nothing timed on the
                    # device = the same kernels and bits in every process
-                   "kernel_table": getattr(model, "tuning_info", None)},
+                   "kernel_table": getattr(model, "tuning_info", None),
+                   # ssd_build_id() of the loaded library recomputed from the checked-out sources (csrc/*.hip|*.h +
+                   # include/ssd_hip.h + the compile flags): equal = the library was built from these sources
+                   "build_id_from_sources": build_id_from_sources()},
         "roofline": {"bound": "mfma", "kernel": "conv_mfma3_kernel (implicit-GEMM tiles, every fp32 product as six v_mfma_f32_16x16x32_bf16 of an exact "
                                                  "3-way operand split) + conv_mfma_kernel / conv_wino_kernel / conv_skinny_kernel (fp32 v_mfma_f32_16x16x4: "
                                                  "implicit-GEMM, Winograd F(2x2,3x3), in-workgroup-split-K tiles), all configs",
@@ -369,8 +384,9 @@ def train_bench(args, hp, get_model, rank, world, dist):
 
     def step():
         yd, yl = train_utils.calculate_actual_outputs(priors, gt, gl, hp)
+        model.plan_gradient_exchange(B)                 # N > 1 (or --force-dist): gradient buckets exchanged as the backward finishes them
         loc, conf, g = model.forward_backward(x, yd, yl)
-        w = parallel.allreduce_gradients(g)
+        w = model.exchange_gradients(g)
         model.apply_gradients(g, 1e-3, 1.0 / w)
         return loc, conf
 
@@ -448,6 +464,22 @@ def kernel_sources_sha16():
     for f in sorted(glob.glob(os.path.join(REPO, "tf-ssd_amd", "csrc", "*.hip")) +
                     glob.glob(os.path.join(REPO, "tf-ssd_amd", "csrc", "*.h"))):
         h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
+def build_id_from_sources():
+    """What csrc/build.sh stamps into the library as ssd_build_id(): sha256 over the kernel sources (the bytes of
+    kernel_sources_sha16), include/ssd_hip.h and the compile-flag line of build.sh."""
+    import glob
+    import hashlib
+    import re
+    h = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(REPO, "tf-ssd_amd", "csrc", "*.hip")) +
+                    glob.glob(os.path.join(REPO, "tf-ssd_amd", "csrc", "*.h"))):
+        h.update(open(f, "rb").read())
+    h.update(open(os.path.join(REPO, "include", "ssd_hip.h"), "rb").read())
+    m = re.search(r'^COMMON="([^"]*)"', open(os.path.join(REPO, "tf-ssd_amd", "csrc", "build.sh")).read(), re.M)
+    h.update(((m.group(1) if m else "") + "\n").encode())
     return h.hexdigest()[:16]
 
 

@@ -12,7 +12,7 @@ REF = "/root/reference"
 OUT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "host_logic.json")
 
 
-def extract(path, names):
+def extract(path, names, extra_ns=None):
     tree = ast.parse(open(path).read())
     keep = []
     for node in tree.body:
@@ -21,6 +21,7 @@ def extract(path, names):
         elif isinstance(node, ast.Assign) and any(isinstance(t, ast.Name) and t.id in names for t in node.targets):
             keep.append(node)
     ns = {"math": math, "os": os}
+    ns.update(extra_ns or {})
     exec(compile(ast.Module(body=keep, type_ignores=[]), path, "exec"), ns)
     return ns
 
@@ -66,11 +67,74 @@ def main():
             valid[b] = True
         except AssertionError:
             valid[b] = False
-    json.dump({"source": "executed from /root/reference/utils/{train_utils,io_utils}.py via ast extraction (make_host_golden.py)",
+    # ---- the remaining TF-free functions on / beside the hot path
+    bb = extract(os.path.join(REF, "utils/bbox_utils.py"), {"get_scale_for_nth_feature_map"})
+    scale_cases = [[k, {}] for k in range(1, 7)] + [[k, {"m": 4}] for k in range(1, 5)] + \
+                  [[k, {"m": 6, "scale_min": 0.1, "scale_max": 0.95}] for k in (1, 3, 6)] + [[2, {"m": 2, "scale_min": 0.15}], [7, {}], [0, {}]]
+    scales = [[k, kw, bb["get_scale_for_nth_feature_map"](k, **kw)] for k, kw in scale_cases]
+    try:
+        bb["get_scale_for_nth_feature_map"](1, m=1)
+        scale_m1 = "no error"
+    except ZeroDivisionError:
+        scale_m1 = "ZeroDivisionError"
+    import argparse, datetime as _dt, types
+
+    class FrozenDatetime(object):                 # `datetime.now()` of the module under test, frozen
+        @staticmethod
+        def now():
+            return _dt.datetime(2020, 1, 2, 3, 4, 5)
+    io2 = extract(os.path.join(REF, "utils/io_utils.py"), {"get_log_path", "handle_args"},
+                  {"datetime": FrozenDatetime, "argparse": argparse})
+    log_paths = [[m, pf, io2["get_log_path"](m, pf)] for m, pf in (("mobilenet_v2", ""), ("vgg16", ""), ("vgg16", "_run7"), ("x", "/y"))]
+    argv_cases = [[], ["-handle-gpu"], ["--backbone", "vgg16"], ["--backbone=mobilenet_v2", "-handle-gpu"], ["--backbone", "resnet50"]]
+    parsed = []
+    old_argv = sys.argv
+    for av in argv_cases:
+        sys.argv = ["prog"] + av
+        a = io2["handle_args"]()
+        parsed.append([av, {k: v for k, v in sorted(vars(a).items())}])
+    bad_argv = []
+    for av in (["--nope"], ["--backbone"]):
+        sys.argv = ["prog"] + av
+        try:
+            devnull = open(os.devnull, "w")
+            old_err, sys.stderr = sys.stderr, devnull
+            try:
+                io2["handle_args"]()
+                bad_argv.append([av, "ok"])
+            finally:
+                sys.stderr = old_err
+        except SystemExit as e:
+            bad_argv.append([av, "SystemExit %s" % e.code])
+    sys.argv = old_argv
+    du = extract(os.path.join(REF, "utils/data_utils.py"), {"get_total_item_size", "get_labels", "get_custom_imgs"})
+    names = ["aeroplane", "bicycle", "bird"]
+    info = types.SimpleNamespace(
+        splits={"train": types.SimpleNamespace(num_examples=2501), "validation": types.SimpleNamespace(num_examples=2510),
+                "test": types.SimpleNamespace(num_examples=4952)},
+        features={"labels": types.SimpleNamespace(names=names)})
+    sizes = [[sp, du["get_total_item_size"](info, sp)] for sp in ("train", "train+validation", "validation", "test")]
+    try:
+        du["get_total_item_size"](info, "all")
+        bad_split = "no error"
+    except AssertionError:
+        bad_split = "AssertionError"
+    with tempfile.TemporaryDirectory() as d:
+        for f in ("b.jpg", "a.png", "c.txt"):
+            open(os.path.join(d, f), "w").close()
+        os.makedirs(os.path.join(d, "sub"))
+        open(os.path.join(d, "sub", "nested.jpg"), "w").close()
+        listed = sorted(os.path.relpath(q, d) for q in du["get_custom_imgs"](d))
+        missing = du["get_custom_imgs"](os.path.join(d, "does_not_exist"))
+    json.dump({"source": "executed from /root/reference/utils/{train_utils,io_utils,bbox_utils,data_utils}.py via ast extraction (make_host_golden.py)",
                "get_hyper_params": hyper, "sticky_img_size_after_override": sticky,
                "scheduler": [[e, tu["scheduler"](e)] for e in epochs],
                "get_step_size": [[t, b, tu["get_step_size"](t, b)] for t, b in steps],
-               "get_model_path": paths, "get_model_path_creates_dir": made_dir, "is_valid_backbone": valid},
+               "get_model_path": paths, "get_model_path_creates_dir": made_dir, "is_valid_backbone": valid,
+               "get_scale_for_nth_feature_map": scales, "get_scale_m1": scale_m1,
+               "get_log_path_at_2020_01_02_03_04_05": log_paths, "handle_args": parsed, "handle_args_bad": bad_argv,
+               "get_total_item_size": sizes, "get_total_item_size_bad_split": bad_split, "get_labels": du["get_labels"](info),
+               "get_custom_imgs_sorted_relative": listed, "get_custom_imgs_missing_dir": missing},
               open(OUT, "w"), indent=1, sort_keys=True)
     print("wrote", OUT)
 

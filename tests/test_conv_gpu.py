@@ -179,6 +179,67 @@ def test_split_bf16_tiles_are_as_accurate_as_the_fp32_mfma():
     assert max(errs["mfma3_"]) <= 1.5 * max(errs["mfma_"]) + 1e-7 and max(errs["mfma3_"]) <= 3e-5        # measured: 1.11e-5 (split-bf16) vs 1.19e-5 (fp32 MFMA)
 
 
+def test_split_bf16_tiles_nonfinite_and_tiny_inputs():
+    """Edge semantics of the split-bf16 tiles (csrc/ssd_bf16x3.h) next to the fp32-MFMA tiles.
+    (1) A non-finite activation: `split1` turns x = +-inf into (h = inf, m = l = NaN) where the fp32 MFMA propagates
+    inf, so the two families may answer inf vs NaN -- the CONTRACT both keep is: every output whose receptive field
+    holds the non-finite input is non-finite, every other output is finite and unchanged (nothing leaks, nothing is
+    silently made finite).  (2) Magnitudes below ~2^-110: the l plane (x - h - m, 2^-16 below x) falls into the
+    bf16 / fp32 denormal range and may be flushed, so a split product keeps >= 16 significand bits instead of 24: the
+    error stays <= 2^-15 RELATIVE to the output scale, i.e. ~1e-35 absolute -- irrelevant to the 1e-4 contract."""
+    import ssd_hip as h
+    lib = h.lib()
+    rng = np.random.default_rng(5)
+    B, H, Cin, Cout = 1, 12, 64, 64
+    x = rng.standard_normal((B, H, H, Cin)).astype(np.float32)
+    w = (rng.standard_normal((3, 3, Cin, Cout)) / np.sqrt(9 * Cin)).astype(np.float32)
+    ref = no.conv2d(x, w, None, 1, 1, "same")
+    xbad = x.copy()
+    xbad[0, 3, 4, 7] = np.inf
+    xbad[0, 9, 2, 33] = np.nan
+    xbad[0, 6, 10, 0] = -np.inf
+    touched = np.zeros((H, H), bool)
+    for (py, px) in ((3, 4), (9, 2), (6, 10)):
+        touched[max(py - 1, 0):py + 2, max(px - 1, 0):px + 2] = True
+    ran = {"mfma_": 0, "mfma3_": 0}
+    for cfg in range(lib.ssd_conv_num_configs()):
+        name = lib.ssd_conv_config_name(cfg)
+        fam = "mfma3_" if name.startswith(b"mfma3_") else ("mfma_" if name.startswith(b"mfma_") else None)
+        if fam is None:
+            continue
+        rc, out = run_conv(xbad, w, None, None, None, 1, 1, (1, 1, 1, 1), cfg=cfg)
+        if rc == -3:
+            continue
+        assert rc == 0, lib.ssd_last_error()
+        o = _np(out)[0]
+        assert not np.isfinite(o[touched]).any(), (name, "a non-finite input was made finite")
+        assert np.isfinite(o[~touched]).all(), (name, "a non-finite input leaked outside its receptive field")
+        assert np.abs(o[~touched] - ref[0][~touched]).max() <= 1e-4, name
+        ran[fam] += 1
+    assert ran["mfma_"] >= 4 and ran["mfma3_"] >= 4
+    # (2) tiny magnitudes: activations ~1e-34 (around 2^-113), O(1) weights
+    tiny = np.float32(1e-34)
+    xt = (x * tiny).astype(np.float32)
+    reft = no.conv2d(xt.astype(np.float64), w.astype(np.float64), None, 1, 1, "same")
+    scale = float(np.abs(reft).max())
+    worst = {"mfma_": 0.0, "mfma3_": 0.0}
+    for cfg in range(lib.ssd_conv_num_configs()):
+        name = lib.ssd_conv_config_name(cfg)
+        fam = "mfma3_" if name.startswith(b"mfma3_") else ("mfma_" if name.startswith(b"mfma_") else None)
+        if fam is None:
+            continue
+        rc, out = run_conv(xt, w, None, None, None, 1, 1, (1, 1, 1, 1), cfg=cfg)
+        if rc == -3:
+            continue
+        assert rc == 0, lib.ssd_last_error()
+        o = _np(out).astype(np.float64)
+        assert np.isfinite(o).all(), name
+        worst[fam] = max(worst[fam], float(np.abs(o - reft).max()) / scale)
+    print("tiny inputs (|x| ~ 1e-34): max error relative to the output scale: fp32 MFMA tiles %.2e, split-bf16 tiles %.2e" % (
+        worst["mfma_"], worst["mfma3_"]))
+    assert worst["mfma3_"] <= 2.0 ** -15 and worst["mfma_"] <= 2.0 ** -15
+
+
 def test_conv2d_splitk_and_strided_output():
     rng = np.random.default_rng(5)
     B, H, Cin, Cout = 2, 10, 1280, 126

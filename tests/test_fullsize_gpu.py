@@ -69,10 +69,11 @@ def _assert_same_detections(b, l, s, rb, rl, rs, v, what):
     each other (rank swap), a score within noise of the 0.5 threshold, or an IoU within noise of
     the 0.5 suppression threshold.  On a row mismatch every oracle row must therefore have its own
     partner among the product's rows (same label, score and box within 1e-4) or be explained by
-    such a borderline decision -- and vice versa."""
+    such a borderline decision -- and vice versa.  Returns the number of detections that needed the borderline
+    explanation (0 = the image matched row for row); the caller bounds and reports how many IMAGES did."""
     vp = int((s > 0).sum())
     if vp == v and np.array_equal(l, rl) and np.abs(s - rs).max() <= 1e-4 and np.abs(b - rb).max() <= 1e-4:
-        return
+        return 0
     used = np.zeros(vp, bool)
     unmatched_ref = []
     for j in range(v):
@@ -91,6 +92,7 @@ def _assert_same_detections(b, l, s, rb, rl, rs, v, what):
         near_iou = same.size > 0 and bool((np.abs(_iou1(box, same) - 0.5) <= 2e-3).any())
         cut_off = vp == 200 or v == 200                 # the top-200 truncation moved by one rank
         assert near_thr or near_iou or cut_off, "%s: unexplained detection (label %g score %.6f)" % (what, lab, sc)
+    return len(extra)
 
 
 def _check_nms_contract(boxes, labels, scores, L, max_total=200, score_thr=0.5):
@@ -158,9 +160,18 @@ def test_full_batch_forward_and_decode(backbone, B, S, subset, subset8):
     _assert_deltas(d[sel], td, hp["variances"])
     tb, tl, ts, tv, ti = co.decode_nms(td, tp, _np(priors), hp["variances"])
     assert tv.min() > 0, "synthetic calibration must leave NMS something to do on every image"
+    borderline = {}
     for j, b in enumerate(sel):
         v = int(tv[j])
-        _assert_same_detections(boxes[b], labels[b], scores[b], tb[j], tl[j], ts[j], v, "image %d" % b)
+        n = _assert_same_detections(boxes[b], labels[b], scores[b], tb[j], tl[j], ts[j], v, "image %d" % b)
+        if n:
+            borderline[b] = n
+    # how often the borderline branch was needed is part of the record (pytest -rA / -s shows it): with the shipped
+    # tables every configuration matched ROW FOR ROW on all 8 images when this bound was written, so a regression
+    # from 0 is visible in the log and more than 2 of the 8 images needing it fails
+    print("end-to-end detections %s B=%d S=%d: %d of %d oracle images needed the borderline branch %s" % (
+        backbone, B, S, len(borderline), len(sel), borderline))
+    assert len(borderline) <= 2, "borderline explanations on %d of %d images: %s" % (len(borderline), len(sel), borderline)
     # (b) determinism and batch-composition independence (same tiles: same bits)
     d2, p2 = m(x)
     np.testing.assert_array_equal(_np(d2), d)

@@ -123,6 +123,50 @@ def test_host_logic_vs_executed_reference(tmp_path, monkeypatch):
                 io_utils.is_valid_backbone(b)
 
 
+def test_tf_free_helpers_vs_executed_reference(tmp_path, monkeypatch):
+    """The remaining TF-free reference functions on / beside the hot path (A1 ``get_scale_for_nth_feature_map``,
+    ``get_log_path``, ``handle_args``, ``get_total_item_size``, ``get_labels``, ``get_custom_imgs``) against outputs
+    of the reference's OWN definitions executed by tests/golden/make_host_golden.py."""
+    import json, time, types
+    from utils import bbox_utils, io_utils, data_utils
+    g = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "host_logic.json")))
+    for k, kw, want in g["get_scale_for_nth_feature_map"]:
+        assert bbox_utils.get_scale_for_nth_feature_map(k, **kw) == want, (k, kw)       # the same float64 expression: exact
+    assert g["get_scale_m1"] == "ZeroDivisionError"
+    with pytest.raises(ZeroDivisionError):
+        bbox_utils.get_scale_for_nth_feature_map(1, m=1)
+    frozen = time.struct_time((2020, 1, 2, 3, 4, 5, 3, 2, 0))
+    monkeypatch.setattr(io_utils.time, "localtime", lambda *a: frozen)
+    for m, pf, want in g["get_log_path_at_2020_01_02_03_04_05"]:
+        assert io_utils.get_log_path(m, pf) == want
+    for argv, want in g["handle_args"]:
+        assert vars(io_utils.handle_args(argv)) == want, argv
+    for argv, want in g["handle_args_bad"]:
+        assert want == "SystemExit 2"
+        with pytest.raises(SystemExit) as e:
+            io_utils.handle_args(argv)
+        assert e.value.code == 2
+    names = g["get_labels"]
+    info = types.SimpleNamespace(
+        splits={"train": types.SimpleNamespace(num_examples=2501), "validation": types.SimpleNamespace(num_examples=2510),
+                "test": types.SimpleNamespace(num_examples=4952)},
+        features={"labels": types.SimpleNamespace(names=names)})
+    for sp, want in g["get_total_item_size"]:
+        assert data_utils.get_total_item_size(info, sp) == want
+        assert data_utils.get_total_item_size({"splits": {"train": 2501, "validation": 2510, "test": 4952}}, sp) == want
+    with pytest.raises(AssertionError):
+        data_utils.get_total_item_size(info, "all")
+    assert data_utils.get_labels(info) == names
+    for f in ("b.jpg", "a.png", "c.txt"):
+        (tmp_path / f).write_bytes(b"")
+    (tmp_path / "sub").mkdir()
+    (tmp_path / "sub" / "nested.jpg").write_bytes(b"")
+    got = [os.path.relpath(q, tmp_path) for q in data_utils.get_custom_imgs(str(tmp_path))]
+    # the reference lists in os.walk order (unspecified); this build sorts: the same SET, one fixed order
+    assert sorted(got) == g["get_custom_imgs_sorted_relative"] and got == sorted(got)
+    assert data_utils.get_custom_imgs(str(tmp_path / "does_not_exist")) == g["get_custom_imgs_missing_dir"]
+
+
 def test_shard_range():
     import parallel
     for n in (0, 1, 7, 64, 4952):
@@ -323,3 +367,23 @@ def test_data_utils_padded_batch_and_custom_image_listing(tmp_path):
     its = list(data_utils.synthetic_voc_items(3, 21, seed=1))
     assert all(it["image"].dtype == np.uint8 and it["image"].ndim == 3 for it in its)
     assert all(it["objects"]["label"].max() <= 19 and len(it["objects"]["bbox"]) == len(it["objects"]["is_difficult"]) for it in its)
+
+
+def test_make_tf_golden_tool_stays_runnable():
+    """tools/make_tf_golden.py is the committed route from "parity unpinned" to "pinned" (it needs TensorFlow and a
+    checkout of the reference, neither exists here): keep it runnable -- it parses, `--help` works without
+    TensorFlow, it takes the reference ONLY from `--reference` (no hard-wired path), and every file it writes is
+    one tests/test_tf_golden.py consumes (and vice versa)."""
+    import ast, re, subprocess
+    tool = os.path.join(REPO, "tools", "make_tf_golden.py")
+    src = open(tool).read()
+    ast.parse(src)
+    r = subprocess.run([sys.executable, tool, "--help"], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and "--reference" in r.stdout
+    r = subprocess.run([sys.executable, tool], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 2 and "--reference" in r.stderr            # required argument, argparse's own error
+    assert "/root/reference" not in src
+    written = set(re.findall(r'"(tf_[a-z_%]+\.npz)"', src))
+    consumer = open(os.path.join(REPO, "tests", "test_tf_golden.py")).read()
+    read = set(re.findall(r'_tf\("(tf_[a-z_%]+\.npz)"', consumer))
+    assert written == read and len(written) >= 6, (written, read)

@@ -20,11 +20,12 @@ compile() {  # src extra-flags
   fi
 }
 [ "$1" = "-f" ] && FORCE=1
-# build id = sha256 of the kernel sources (same bytes, same order as bench.py's kernel_sources_sha16):
+# build id = sha256 of the kernel sources (same bytes, same order as bench.py's kernel_sources_sha16; the whole recipe: bench.py build_id_from_sources):
 # shipped tuning tables and PMC traffic passes record the build they were measured on
-BID=$(LC_ALL=C ls *.hip *.h | LC_ALL=C sort | xargs cat | sha256sum | cut -c1-16)
+# (+ the public header and the compile flags: either changes the library without touching a kernel source)
+BID=$( { LC_ALL=C ls *.hip *.h | LC_ALL=C sort | xargs cat; cat ../../include/ssd_hip.h; echo "$COMMON"; } | sha256sum | cut -c1-16)
 echo "#define SSD_BUILD_ID \"$BID\"" > build/build_id.h.new
-if cmp -s build/build_id.h.new build/build_id.h; then rm build/build_id.h.new; else mv build/build_id.h.new build/build_id.h; touch ssd_core.hip.stamp 2>/dev/null; rm -f build/ssd_core.o ssd_core.hip.stamp; fi
+if cmp -s build/build_id.h.new build/build_id.h; then rm build/build_id.h.new; else mv build/build_id.h.new build/build_id.h; rm -f build/ssd_core.o; fi
 # box math: separately-rounded fp32 ops (bit-exact indices vs the oracle)
 compile ssd_core.hip
 compile ssd_bbox.hip -ffp-contract=off -fhip-fp32-correctly-rounded-divide-sqrt

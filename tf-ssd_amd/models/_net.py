@@ -12,6 +12,7 @@ import ssd_hip as _h
 
 # options that change which kernel configurations finalize may choose (the memo is per option set)
 _TABLE_OPTIONS = ("use_wino",)
+_STALE_WARNED = set()
 
 
 class SSDModel(object):
@@ -50,6 +51,9 @@ class SSDModel(object):
 
     def __del__(self):
         try:
+            if getattr(self, "_comm_stream", None) is not None:
+                _h.free_stream(self._comm_stream)
+                self._comm_stream = None
             if getattr(self, "_net", None):
                 _h.lib().ssd_net_destroy(self._net)
                 self._net = None
@@ -204,9 +208,19 @@ class SSDModel(object):
         _h.check(lib.ssd_net_tuning_stats(self._net, ctypes.byref(a), ctypes.byref(b)), "ssd_net_tuning_stats")
         table = self.get_tuning()
         hdr = tuning.header(text or "")
+        this_build = lib.ssd_build_id().decode()
+        # a table measured on another build of the kernels still pins VALID choices (same bits in every process), but
+        # they may no longer be the fastest: say so instead of reporting it as current
+        stale = bool(text) and hdr.get("build") not in (None, this_build)
         self.tuning_info = {"key": key, "source": source, "table_sha16": tuning.sha16(table), "layers_from_table": a.value,
                             "choices_timed_on_device": b.value, "reproducible": b.value == 0,
-                            "table_build": hdr.get("build"), "this_build": lib.ssd_build_id().decode()}
+                            "table_build": hdr.get("build"), "this_build": this_build, "stale": stale}
+        if stale and os.environ.get("SSD_HIP_WARN_STALE_TABLE", "1") != "0" and key not in _STALE_WARNED:
+            _STALE_WARNED.add(key)
+            import warnings
+            warnings.warn("kernel table %s (%s) was measured on build %s, this library is %s: choices stay valid and "
+                          "reproducible but may be slower than a re-measured table (tools/make_tuning_tables.py)" % (
+                              key, source, hdr.get("build"), this_build))
         if explicit is None:
             tuning.memo_put(key, opts, table)
         if path and not os.path.exists(path):
@@ -340,6 +354,7 @@ class SSDModel(object):
             _h.check(lib.ssd_net_train_begin(self._net, B), "ssd_net_train_begin")
             self._train_batch = B
             self._finalized_for = 0
+            self._bucket_starts = None         # a new training state has no bucket events: the plan is re-made
         P = lib.ssd_net_trainable_floats(self._net)
         if getattr(self, "_grads", None) is None or self._grads.numel() != P:
             self._grads = torch.empty((P,), dtype=torch.float32, device=x.device)
@@ -365,27 +380,39 @@ class SSDModel(object):
         averaged (batch data-parallel).  Returns (loss, loc_loss, conf_loss) host
         floats of THIS rank's batch (Keras logs the batch means; ``loss`` includes the regularisation term,
         the two components do not)."""
-        import parallel
-        import torch.distributed as dist
-        multi = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
-        n_buckets = int(os.environ.get("SSD_HIP_GRAD_BUCKETS", "4")) if multi else 0
-        if n_buckets > 1:
-            self._plan_gradient_buckets(images.shape[0], n_buckets)
+        self.plan_gradient_exchange(images.shape[0])
+        # the regularisation term at the weights this batch is evaluated with, like Keras.  Taken BEFORE the step is
+        # issued (the weights do not change until apply_gradients): its device round trip (VGG16 only) then sits
+        # between two steps instead of between the backward and the first gradient bucket's all-reduce
+        reg = self.regularization_loss()
         loc, conf, g = self.forward_backward(images, targets[0], targets[1])
-        reg = self.regularization_loss()               # at the weights this batch was evaluated with, like Keras
-        if n_buckets > 1:
-            # the exchange of a bucket starts when the backward has finished it (heads / extras first) and runs on
-            # its own stream beside the backward of the backbone
-            lib = _h.lib()
-            world = parallel.allreduce_gradients_as_ready(
-                g, self._bucket_starts,
-                wait_bucket=lambda k, st: _h.check(lib.ssd_net_train_wait_bucket(self._net, k, _h.vp(st.cuda_stream)), "wait_bucket"),
-                comm_stream=self._comm_stream)
-        else:
-            world = parallel.allreduce_gradients(g)
+        world = self.exchange_gradients(g)
         self.apply_gradients(g, learning_rate, 1.0 / world)
         lm, cm = float(loc.mean().item()), float(conf.mean().item())
         return lm + cm + reg, lm, cm
+
+    def plan_gradient_exchange(self, batch):
+        """Before ``forward_backward`` of a data-parallel step: plan the gradient buckets (one completion event each
+        in the native backward) when more than one rank takes part (or SSD_HIP_FORCE_DIST=1)."""
+        import parallel
+        import torch.distributed as dist
+        multi = dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or parallel.force_collectives())
+        self._n_buckets = int(os.environ.get("SSD_HIP_GRAD_BUCKETS", "4")) if multi else 0
+        if self._n_buckets > 1:
+            self._plan_gradient_buckets(batch, self._n_buckets)
+
+    def exchange_gradients(self, g):
+        """After ``forward_backward``: SUM all-reduce of the flat gradient over the ranks; returns the world size.
+        With planned buckets the exchange of a bucket starts when the backward has finished it (heads / extras
+        first) and runs on its own stream beside the backward of the backbone."""
+        import parallel
+        if getattr(self, "_n_buckets", 0) > 1 and getattr(self, "_bucket_starts", None) is not None:
+            lib = _h.lib()
+            return parallel.allreduce_gradients_as_ready(
+                g, self._bucket_starts,
+                wait_bucket=lambda k, st: _h.check(lib.ssd_net_train_wait_bucket(self._net, k, _h.vp(st.cuda_stream)), "wait_bucket"),
+                comm_stream=self._comm_stream)
+        return parallel.allreduce_gradients(g)
 
     def _plan_gradient_buckets(self, batch, n_buckets):
         """``ssd_net_train_set_buckets``: equal contiguous buckets of the flat gradient, one completion event each."""
@@ -396,9 +423,9 @@ class SSDModel(object):
             self._train_batch = int(batch)
             self._finalized_for = 0
             self._bucket_starts = None
-        if getattr(self, "_bucket_starts", None) is None or len(self._bucket_starts) != n_buckets:
-            P = lib.ssd_net_trainable_floats(self._net)
-            starts = parallel.bucket_starts(P, n_buckets)
+        P = lib.ssd_net_trainable_floats(self._net)
+        starts = parallel.bucket_starts(P, n_buckets)          # may hold fewer than n_buckets starts (small P)
+        if getattr(self, "_bucket_starts", None) is None or list(self._bucket_starts) != list(starts):
             arr = (ctypes.c_long * len(starts))(*starts)
             _h.check(lib.ssd_net_train_set_buckets(self._net, len(starts), arr), "ssd_net_train_set_buckets")
             self._bucket_starts = starts

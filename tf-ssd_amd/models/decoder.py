@@ -161,6 +161,10 @@ class DecoderModel(object):
             if best_t is None or t < best_t:
                 best, best_t = (a, b), t
         self._lane_streams[0], self._lane_streams[1] = cands[best[0]], cands[best[1]]
+        torch.cuda.synchronize()
+        for k, c in enumerate(cands):                  # the losing candidates are native streams of ours: destroy them
+            if k not in best:
+                _h.free_stream(c)
         # steady state of the chosen pair against one lane alone (the short trials flatter the pairing: with
         # 8 / 16 hardware queues a pair measured 1.87 ms in its trial and 1.98 ms sustained, 1.95 alone);
         # where two lanes do not pay, submit() falls back to one step at a time
@@ -238,6 +242,25 @@ class DecoderModel(object):
             t.record_stream(st)
         d.last_valid_detections = v
         return b, l, s
+
+    def close(self):
+        """Release the lanes: their replicas of the net (arena, scratch) and their native streams."""
+        if self._lane_streams:
+            try:
+                torch.cuda.synchronize()
+            except Exception:
+                pass
+        for st in self._lane_streams:
+            _h.free_stream(st)
+        self._lane_streams = []
+        self._lane_models = []
+        self._lanes_calibrated = False
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
     def wait(self):
         """The caller's stream waits for every lane (outputs of all submitted steps are then ordered

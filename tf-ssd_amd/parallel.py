@@ -8,6 +8,20 @@ import torch
 import torch.distributed as dist
 
 
+def force_collectives():
+    """``SSD_HIP_FORCE_DIST=1``: take the multi-rank code paths (communicator, collectives, bucketed exchange on the
+    communication stream) whenever a process group is initialised, also at world size 1 -- how the N > 1 paths are
+    exercised on a one-GPU box (``bench.py --force-dist``, ``tests/test_train.py``)."""
+    return os.environ.get("SSD_HIP_FORCE_DIST", "0") == "1"
+
+
+def _single():
+    """True when no collective is needed: no process group, or one rank and collectives not forced."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return True
+    return dist.get_world_size() == 1 and not force_collectives()
+
+
 def env_rank():
     return int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
 
@@ -15,7 +29,11 @@ def env_rank():
 def init_distributed(backend=None):
     """Initialise the default process group from the torchrun environment (no-op for world 1)."""
     rank, local_rank, world = env_rank()
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or force_collectives()) and not dist.is_initialized():
+        if world == 1:           # forced single-rank group: torchrun did not provide the rendezvous
+            os.environ.setdefault("MASTER_PORT", "29531")
+            os.environ.setdefault("RANK", "0")
+            os.environ.setdefault("WORLD_SIZE", "1")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if backend is None:
             backend = "nccl" if torch.cuda.is_available() else "gloo"
@@ -37,7 +55,7 @@ def shard_range(n, rank, world):
 def gather_detections(boxes, labels, scores, n_total=None):
     """All-gather per-rank detections ([b,T,4], [b,T], [b,T]) in rank order -> full batch on
     every rank.  Shards may differ in size by one image (padded for the collective)."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    if _single():
         return boxes, labels, scores
     world = dist.get_world_size()
     T = boxes.shape[1]
@@ -58,7 +76,7 @@ def gather_detections(boxes, labels, scores, n_total=None):
 
 def max_over_ranks(value):
     """Max of a host float over all ranks (bench timing)."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    if _single():
         return float(value)
     dev = "cuda" if dist.get_backend() == "nccl" else "cpu"
     t = torch.tensor([float(value)], dtype=torch.float64, device=dev)
@@ -83,7 +101,7 @@ def allreduce_gradients(flat, bucket_floats=None):
     """In-place SUM all-reduce of the flat gradient tensor over the default process group.
     Returns the world size (the caller scales by 1/world in the optimiser: Keras' batch mean over
     the global batch for equal shards).  No-op (returns 1) without an initialised group."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    if _single():
         return 1
     works = [dist.all_reduce(flat[lo:hi], op=dist.ReduceOp.SUM, async_op=True)
              for lo, hi in gradient_buckets(flat.numel(), bucket_floats)]
@@ -109,7 +127,7 @@ def allreduce_gradients_as_ready(flat, starts, wait_bucket=None, comm_stream=Non
     completion event (``ssd_net_train_wait_bucket``), while the backward of the earlier layers is still running
     on the caller's stream.  xGMI is a point-to-point mesh: a handful of multi-megabyte buckets keeps every
     message large.  Returns the world size; the caller's stream waits for every bucket before returning."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    if _single():
         return 1
     n = flat.numel()
     bounds = list(starts) + [n]
@@ -130,7 +148,7 @@ def allreduce_gradients_as_ready(flat, starts, wait_bucket=None, comm_stream=Non
 
 def mean_over_ranks(value):
     """Mean of a host float over all ranks (validation loss of a data-parallel fit)."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    if _single():
         return float(value)
     dev = "cuda" if dist.get_backend() == "nccl" else "cpu"
     t = torch.tensor([float(value)], dtype=torch.float64, device=dev)

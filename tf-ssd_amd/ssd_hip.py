@@ -174,7 +174,21 @@ def new_stream(high_priority=False):
     h = lib().ssd_stream_create(1 if high_priority else 0)
     if not h:
         raise SsdHipError("ssd_stream_create: %s" % lib().ssd_last_error().decode())
-    return torch.cuda.ExternalStream(h)
+    st = torch.cuda.ExternalStream(h)
+    st._ssd_handle = h          # ExternalStream does not own the native stream: free_stream() destroys it
+    return st
+
+
+def free_stream(st):
+    """Destroy a stream made by ``new_stream`` (idempotent).  The caller guarantees that nothing is queued on it
+    any more (``st.synchronize()`` first when in doubt)."""
+    h = getattr(st, "_ssd_handle", None)
+    if h:
+        st._ssd_handle = None
+        try:
+            lib().ssd_stream_destroy(vp(h))
+        except Exception:
+            pass
 
 
 def to_dev(x, dtype=torch.float32):

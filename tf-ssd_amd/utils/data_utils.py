@@ -54,7 +54,10 @@ def preprocess_batch(images_u8, final_height, final_width):
 
 
 def get_labels(info=None):
-    """reference utils/data_utils.py:70-78 (``info.features["labels"].names`` for VOC)."""
+    """reference utils/data_utils.py:61-69: ``info.features["labels"].names`` of a tfds info object; without one
+    (tfds is not available here) the 20 VOC class names the reference's datasets carry."""
+    if info is not None and hasattr(info, "features"):
+        return info.features["labels"].names
     return list(VOC_LABELS)
 
 
@@ -66,13 +69,19 @@ def get_dataset(name, split, data_dir="~/tensorflow_datasets"):
 
 
 def get_total_item_size(info, split):
-    """reference utils/data_utils.py:47-59 (``info`` here: a dict ``{"splits": {name: count}}`` or an int)."""
+    """reference utils/data_utils.py:47-59.  ``info``: a tfds info object (``info.splits[name].num_examples``, the
+    reference's argument), or -- tfds is not available here -- a dict ``{"splits": {name: count}}`` or an int."""
     assert split in ["train", "train+validation", "validation", "test"]
     if isinstance(info, int):
         return info
+    splits = info.splits if hasattr(info, "splits") else info["splits"]
+
+    def count(name):
+        v = splits[name]
+        return v.num_examples if hasattr(v, "num_examples") else v
     if split == "train+validation":
-        return info["splits"]["train"] + info["splits"]["validation"]
-    return info["splits"][split]
+        return count("train") + count("validation")
+    return count(split)
 
 
 def get_custom_imgs(custom_image_path):
