@@ -49,8 +49,18 @@ PEAK_SPLIT_BF16_TFLOPS = PEAK_BF16_MFMA_TFLOPS / 6.0
 
 
 def matrix_peak(config):
-    """fp32-equivalent matrix-core peak of a conv kernel family (by config name)."""
+    """Matrix-core peak of a conv kernel family (by config name): fp32 MFMA tiles, split-bf16 tiles (fp32 results through
+    six bf16 products: fp32-equivalent = dense bf16 / 6), bf16 tiles (--dtype bf16: one product, the dense bf16 peak)."""
+    if config.startswith("bf16_"):
+        return PEAK_BF16_MFMA_TFLOPS
     return PEAK_SPLIT_BF16_TFLOPS if config.startswith("mfma3_") else PEAK_FP32_MFMA_TFLOPS
+
+
+def fused_peak(config):
+    """... of a fused inverted-residual kernel family (ssd_net_layer_config of a fused layer)."""
+    if config.endswith("_bf16"):
+        return PEAK_BF16_MFMA_TFLOPS
+    return PEAK_SPLIT_BF16_TFLOPS if config == "band3" else PEAK_FP32_MFMA_TFLOPS
 
 
 def main():
@@ -69,6 +79,13 @@ def main():
     ap.add_argument("--no-overlap", action="store_true", help="profiling runs: no intra-step side streams (option overlap_heads 0), so per-kernel durations are uncontended")
     ap.add_argument("--layers", action="store_true", help="also print the per-layer table to stderr")
     ap.add_argument("--train", action="store_true", help="time the training step (SURVEY 8f N1) instead of inference")
+    ap.add_argument("--dtype", default="f32", choices=["f32", "bf16"],
+                    help="f32 (default: the reference's arithmetic, BASELINE configs[1] / [2]) or bf16 (configs[3] / [4]: every matrix "
+                         "operand of the dense / 1x1 convs rounded once to bf16, one bf16 MFMA per product, fp32 accumulation "
+                         "and epilogues; activations stay fp32 in HBM)")
+    ap.add_argument("--repeats", type=int, default=5,
+                    help="the K-step timed region is run this many times (barrier + synchronize around each); `value` / "
+                         "`ms_per_step` come from the MEDIAN region, `timing_spread` reports min / median / max")
     ap.add_argument("--force-dist", action="store_true",
                     help="take the N > 1 code paths at world size 1: RCCL communicator alive (init, first collective, barriers, "
                          "MAX-reduce of the time; --train: bucketed gradient all-reduce on the communication stream)")
@@ -139,7 +156,7 @@ def main():
         hp["feature_map_shapes"] = fm
     if args.train:
         return train_bench(args, hp, get_model, rank, world, dist)
-    model = get_model(hp, max_batch=B)
+    model = get_model(hp, max_batch=B, precision="bf16" if args.dtype == "bf16" else "fp32")
     if args.no_overlap:
         model.set_option("overlap_heads", 0)
     weights = data_utils.synthetic_weights(model, seed=1)
@@ -165,8 +182,8 @@ def main():
                 out = dm(x)
         return out
 
-    def timed(dm, lanes):
-        run_steps(dm, max(args.warmup, 2 * lanes), lanes)
+    def region(dm, lanes):
+        """EXACTLY K steps between barrier + synchronize on both sides."""
         torch.cuda.synchronize()
         barrier()
         torch.cuda.synchronize()
@@ -177,31 +194,38 @@ def main():
         torch.cuda.synchronize()
         return time.perf_counter() - t0
 
-    elapsed = timed(decoder_model, args.lanes)
+    def reduce_max(v):
+        if dist is None:
+            return v
+        t = torch.tensor([v], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def timed(dm, lanes, repeats=1):
+        """W untimed warm-up steps, then `repeats` timed regions of K steps each (a 20-step region is ~27 ms: one
+        region alone is at the mercy of a clock ramp).  Every region's time is the MAX over ranks; returns all."""
+        run_steps(dm, max(args.warmup, 2 * lanes), lanes)
+        return [reduce_max(region(dm, lanes)) for _ in range(max(1, repeats))]
+
+    regions = timed(decoder_model, args.lanes, args.repeats)
+    elapsed = sorted(regions)[len(regions) // 2]            # the median region is the headline
     # the other mode beside it (informational): two batches in flight when the headline is one step at a time,
     # one step at a time when the headline keeps two in flight
     other = None
     if not args.no_other_leg:
         if args.lanes == 1:
             dm2 = get_decoder_model(model, priors, hp, lanes=3)
-            e2 = timed(dm2, 3)
+            e2 = sorted(timed(dm2, 3, 3))[1]
             other = {"mode": "three batches in flight (three net replicas on three in-order streams, DecoderModel.submit)",
                      "ms_per_step": 1e3 * e2 / args.steps, "images_per_sec": world * B * args.steps / e2,
                      "lane_calibration": getattr(dm2, "lane_calibration", None)}
             del dm2
         else:
-            torch.cuda.synchronize()
-            t1 = time.perf_counter()
-            for _ in range(args.steps):
-                decoder_model(x)
-            torch.cuda.synchronize()
-            e1 = time.perf_counter() - t1
+            r1 = sorted(timed(decoder_model, 1, 3))
+            e1 = r1[1]
             other = {"mode": "one step at a time", "ms_per_step": 1e3 * e1 / args.steps,
-                     "images_per_sec": world * B * args.steps / e1}
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+                     "images_per_sec": world * B * args.steps / e1,
+                     "ms_per_step_min_median_max": [1e3 * v / args.steps for v in (r1[0], r1[1], r1[-1])]}
     valid = decoder_model.decoder.last_valid_detections
     mean_det = float(valid.float().mean().item())
 
@@ -212,7 +236,7 @@ def main():
     info, nfw = model.read_timing(B)
     model.set_timing(False)
     # the dense-conv family on the fp32 matrix cores: implicit-GEMM tiles and Winograd F(2x2,3x3) tiles
-    mfma = [r for r in info if r["kind"] == "conv" and r["config"].startswith(("mfma_", "mfma3_", "wino_", "skinny_")) and r["flops"] > 0]
+    mfma = [r for r in info if r["kind"] == "conv" and r["config"].startswith(("mfma_", "mfma3_", "bf16_", "wino_", "skinny_")) and r["flops"] > 0]
     mfma_ms = sum(r["ms"] for r in mfma)
     mfma_flops = sum(r["flops"] for r in mfma)
     mfma_exec = sum(r["executed_flops"] for r in mfma)
@@ -227,6 +251,8 @@ def main():
             k = "conv_winograd"
         elif k == "conv" and r["config"].startswith("mfma3_"):
             k = "conv_split_bf16"
+        elif k == "conv" and r["config"].startswith("bf16_"):
+            k = "conv_bf16"
         elif k == "conv" and not r["config"].startswith(("mfma_", "skinny_")):
             k = "conv_direct"
         kinds[k] = kinds.get(k, 0.0) + r["ms"]
@@ -244,6 +270,9 @@ def main():
     fused = [r for r in info if r["kind"] == "fused" and r["flops"] > 0]
     fused_ms = sum(r["ms"] for r in fused)
     fused_flops = sum(r["flops"] for r in fused)
+    # each fused block priced at the peak of ITS matrix instruction (band3 = split-bf16 row-band kernel, blocks 3-6)
+    fused_ideal_ms = sum(r["flops"] / (fused_peak(r["config"]) * 1e12) * 1e3 for r in fused)
+    fused_split = [r for r in fused if fused_peak(r["config"]) != PEAK_FP32_MFMA_TFLOPS]
     step_flops = sum(r["flops"] for r in info)           # algorithmic conv FLOPs of the whole step
     step_tflops = step_flops / (elapsed / args.steps) / 1e12
     if args.layers and rank == 0:
@@ -290,16 +319,22 @@ def main():
         "steps": args.steps,
         "warmup": args.warmup,
         "ms_per_step": 1e3 * elapsed / args.steps,
+        # the K-step region repeated: `value` / `ms_per_step` are the MEDIAN region's (max over ranks per region)
+        "timing_spread": {"repeats": len(regions), "ms_per_step_min": 1e3 * min(regions) / args.steps,
+                          "ms_per_step_median": 1e3 * elapsed / args.steps, "ms_per_step_max": 1e3 * max(regions) / args.steps,
+                          "images_per_sec_min_median_max": [world * B * args.steps / max(regions), world * B * args.steps / elapsed,
+                                                            world * B * args.steps / min(regions)]},
         # informational: the same K steps in the OTHER launch mode (see --lanes)
         "other_mode": other,
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,
-        "dtype": "f32",
+        "dtype": args.dtype,
         "data": "synthetic (seeded uniform [0,1) images, seeded random weights; no dataset/checkpoint offline)",
-        "config": {"workload": "SSD%d %s inference, batch=%d per GPU, %dx%d fp32, fwd + decode/NMS (BASELINE.json configs[%d])" % (
-                       hp["img_size"], args.backbone, B, hp["img_size"], hp["img_size"],
-                       (1 if args.backbone == "mobilenet_v2" else 2) if hp["img_size"] == 300 else 4),
+        "config": {"workload": "SSD%d %s inference, batch=%d per GPU, %dx%d %s, fwd + decode/NMS (BASELINE.json configs[%d]%s)" % (
+                       hp["img_size"], args.backbone, B, hp["img_size"], hp["img_size"], "fp32" if args.dtype == "f32" else "bf16",
+                       (1 if args.backbone == "mobilenet_v2" else 2) if hp["img_size"] == 300 else 4,
+                       "" if (args.dtype == "bf16") == (hp["img_size"] != 300) else " shape, in %s" % args.dtype),
                    "global_batch": world * B, "priors": model.num_priors, "labels": hp["total_labels"],
                    "mean_detections_per_image": mean_det, "nms_active": mean_det > 0, "parallelism": "batch-sharded x%d, no collective" % world,
                    "batches_in_flight_per_gpu": args.lanes,
@@ -326,6 +361,7 @@ def main():
                      "frac": frac, "frac_kind": "sum(executed FLOPs / peak of the layer's matrix instruction) / measured time",
                      "peak_detail": {"fp32_mfma": PEAK_FP32_MFMA_TFLOPS, "bf16_mfma_dense": PEAK_BF16_MFMA_TFLOPS,
                                      "split_bf16_fp32_equivalent": PEAK_SPLIT_BF16_TFLOPS,
+                                     "bf16_layers": len([r for r in mfma if r["config"].startswith("bf16_")]),
                                      "split_bf16_layers": len(split), "split_bf16_ms_per_step": sum(r["ms"] for r in split),
                                      "split_bf16_executed_gflop_per_step": sum(r["executed_flops"] for r in split) / 1e9},
                      "achieved_algorithmic": achieved, "frac_algorithmic_vs_fp32_mfma_peak": achieved / PEAK_FP32_MFMA_TFLOPS,
@@ -342,13 +378,20 @@ def main():
                          "achieved_algorithmic": dom["flops"] / (dom["ms"] * 1e-3) / 1e12},
                      # the whole step (every kernel, incl. softmax/decode/NMS time) against the same peak, algorithmic FLOPs
                      "achieved_step": step_tflops, "frac_step_vs_fp32_mfma_peak": step_tflops / PEAK_FP32_MFMA_TFLOPS,
+                     # ... and against the peak of the instruction most of the step's FLOPs now run on (six bf16 MFMAs per product)
+                     "frac_step_vs_split_bf16_peak": step_tflops / PEAK_SPLIT_BF16_TFLOPS,
+                     "frac_step_vs_bf16_peak": step_tflops / PEAK_BF16_MFMA_TFLOPS,
                      "algorithmic_gflop_per_step_all": step_flops / 1e9},
         # the other half of the step: whole-block / depthwise+project / stem kernels (MFMA + VALU depthwise)
-        # (blocks 3-6 run the split-bf16 band kernel; the family is priced against the fp32 MFMA peak all the same)
+        # `frac` = matrix time at peak / measured time with every block priced at the peak of its instruction (the
+        # split-bf16 row-band kernel of blocks 3-6 at 419.5, the fp32-MFMA kernels at 157.3); `peak` is the blend
         "roofline_fused": {"bound": "mfma", "kernel": "mbv2_stem_kernel + mbv2_band_block_kernel + mbv2_band3_block_kernel + mbv2_image_block_kernel + dwproj8_kernel (fused inverted-residual family)",
                            "achieved": fused_flops / (fused_ms * 1e-3) / 1e12 if fused_ms > 0 else None,
-                           "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                           "frac": (fused_flops / (fused_ms * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS) if fused_ms > 0 else None,
+                           "peak": (fused_flops / (fused_ideal_ms * 1e-3) / 1e12) if fused_ideal_ms > 0 else PEAK_FP32_MFMA_TFLOPS,
+                           "unit": "TFLOP/s",
+                           "frac": (fused_ideal_ms / fused_ms) if fused_ms > 0 else None,
+                           "frac_vs_fp32_mfma_peak": (fused_flops / (fused_ms * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS) if fused_ms > 0 else None,
+                           "split_bf16_blocks": [r["name"] for r in fused_split],
                            "launches_per_step": len(fused), "kernel_ms_per_step": fused_ms,
                            "algorithmic_gflop_per_step": fused_flops / 1e9},
         "gpu_ms_per_step_by_kind": {k: round(v, 4) for k, v in sorted(kinds.items())},
@@ -357,10 +400,8 @@ def main():
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(args.backbone, hp, weights, priors.cpu().numpy(), args.cpu_sample)
-    if rank == 0:
-        print(json.dumps(result), flush=True)
-    if dist is not None:
-        dist.destroy_process_group()
+    decoder_model.close()
+    emit(result, rank, dist)
 
 
 def train_bench(args, hp, get_model, rank, world, dist):
@@ -374,7 +415,7 @@ def train_bench(args, hp, get_model, rank, world, dist):
     from utils import bbox_utils, data_utils, train_utils
     from ssd_loss import CustomLoss
     B = args.batch or 32
-    model = get_model(hp, max_batch=B)
+    model = get_model(hp, max_batch=B, precision="bf16" if args.dtype == "bf16" else "fp32")
     cl = CustomLoss(hp["neg_pos_ratio"], hp["loc_loss_alpha"])
     model.compile(learning_rate=1e-3, loss=[cl.loc_loss_fn, cl.conf_loss_fn])
     priors = bbox_utils.generate_prior_boxes(hp["feature_map_shapes"], hp["aspect_ratios"])
@@ -393,41 +434,68 @@ def train_bench(args, hp, get_model, rank, world, dist):
     for _ in range(max(args.warmup, 1)):
         loc, conf = step()
     first = float((loc + conf).mean().item())
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        loc, conf = step()
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    regions = []
+    for _ in range(max(1, args.repeats)):                     # K steps per region, barrier + synchronize on both sides
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            loc, conf = step()
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        e = time.perf_counter() - t0
+        if dist is not None:
+            t = torch.tensor([e], dtype=torch.float64, device="cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            e = float(t.item())
+        regions.append(e)
+    elapsed = sorted(regions)[len(regions) // 2]
     last = float((loc + conf).mean().item())
     fwd_gflop = (2.026 if args.backbone == "mobilenet_v2" else 62.747) * B     # conv MACs x 2 per image (forward)
     step_tflops = 3.0 * fwd_gflop * 1e9 / (elapsed / args.steps) / 1e12      # forward + backward-data + backward-weights
+    # what the matrix cores were actually handed, per instruction family (ssd_net_train_matrix_flops), each priced at
+    # the peak of its instruction: fp32-MFMA convs and weight gradients at 157.3, split-bf16 conv tiles at 419.5
+    import ctypes
+    mf = (ctypes.c_double * 3)()
+    ssd_hip.check(ssd_hip.lib().ssd_net_train_matrix_flops(model._net, mf), "train_matrix_flops")
+    peak1 = PEAK_BF16_MFMA_TFLOPS if args.dtype == "bf16" else PEAK_SPLIT_BF16_TFLOPS        # the bf16-pipe family of this dtype
+    ideal_ms = 1e3 * ((mf[0] + mf[2]) / (PEAK_FP32_MFMA_TFLOPS * 1e12) + mf[1] / (peak1 * 1e12))
+    ms_step = 1e3 * elapsed / args.steps
+    issued_tflops = (mf[0] + mf[1] + mf[2]) / (ms_step * 1e-3) / 1e12
     result = {
         "metric": "images/sec SSD300 (%s) training step" % ("MobileNetV2" if args.backbone == "mobilenet_v2" else "VGG16"),
         "value": world * B * args.steps / elapsed,
         "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f32", "data": "synthetic (seeded images + ground truth, Keras-default initial weights)",
-        "config": {"workload": "SSD300 %s training, batch=%d per GPU, fp32, target assignment + fwd + loss + bwd + "
-                               "grad all-reduce + Adam (BASELINE.json configs[3] shape; fp32 instead of bf16)" % (args.backbone, B),
+        "timing_spread": {"repeats": len(regions), "ms_per_step_min": 1e3 * min(regions) / args.steps,
+                          "ms_per_step_median": 1e3 * elapsed / args.steps, "ms_per_step_max": 1e3 * max(regions) / args.steps},
+        "dtype": args.dtype, "data": "synthetic (seeded images + ground truth, Keras-default initial weights)",
+        "config": {"workload": "SSD300 %s training, batch=%d per GPU, %s, target assignment + fwd + loss + bwd + "
+                               "grad all-reduce + Adam (BASELINE.json configs[3] shape%s)" % (
+                                   args.backbone, B, "fp32" if args.dtype == "f32" else "bf16 forward / backward-data convs, fp32 master weights / weight gradients / Adam",
+                                   "; fp32 instead of bf16" if args.dtype == "f32" else ""),
                    "global_batch": world * B, "parallelism": "batch-DP x%d, RCCL all-reduce of %d fp32 gradients" % (
                        world, ssd_hip.lib().ssd_net_trainable_floats(model._net)),
                    "loss_first_step": first, "loss_last_step": last},
         # whole step against the fp32 MFMA peak (the convs the cost model hands to the split-bf16 tiles run above that
         # rate; the step is bound by the elementwise / BatchNorm passes)
+        # `frac` = time the matrix cores would need at peak for the FLOPs the step issued (each family at the peak of
+        # its instruction) over the measured step; `peak` is the blend (achieved / frac).  The 3x-forward algorithmic
+        # figure against the fp32 MFMA peak is kept beside it.
         "roofline": {"bound": "mfma", "kernel": "training step (conv fwd + dgrad via conv_mfma_kernel / conv_mfma3_kernel, wgrad_mfma_kernel)",
-                     "achieved": step_tflops, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                     "frac": step_tflops / PEAK_FP32_MFMA_TFLOPS, "traffic": None,
+                     "achieved": issued_tflops, "peak": issued_tflops / (ideal_ms / ms_step) if ideal_ms > 0 else PEAK_FP32_MFMA_TFLOPS,
+                     "unit": "TFLOP/s", "frac": ideal_ms / ms_step, "traffic": None,
+                     "frac_kind": "sum(issued FLOPs / peak of the family's matrix instruction) / measured step time",
+                     "issued_gflop_per_step": {"conv_fp32_mfma": mf[0] / 1e9, ("conv_bf16" if args.dtype == "bf16" else "conv_split_bf16"): mf[1] / 1e9,
+                                               "wgrad_fp32_mfma": mf[2] / 1e9},
+                     "peak_detail": {"fp32_mfma": PEAK_FP32_MFMA_TFLOPS, "split_bf16_fp32_equivalent": PEAK_SPLIT_BF16_TFLOPS,
+                                     "bf16_mfma_dense": PEAK_BF16_MFMA_TFLOPS},
+                     "achieved_algorithmic_3x_forward": step_tflops,
+                     "frac_algorithmic_vs_fp32_mfma_peak": step_tflops / PEAK_FP32_MFMA_TFLOPS,
                      "algorithmic_gflop_per_step": 3.0 * fwd_gflop},
     }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -450,10 +518,25 @@ def train_bench(args, hp, get_model, rank, world, dist):
         result["cpu_baseline"] = {"value": n * passes / dt, "unit": "images/sec", "cores": threads, "host_cores": os.cpu_count(),
                                   "kind": "port", "sample": "%d passes of the oracle's forward + loss + backward on %d images (torch-CPU "
                                   "autograd, no optimiser step; TensorFlow itself is not installable here)" % (passes, n)}
+    emit(result, rank, dist)
+
+
+def emit(result, rank, dist):
+    """Rank 0 prints the ONE JSON line as the LAST line of the job's stdout.  RCCL writes a version banner through C
+    stdio when its communicator comes up; redirected to a pipe that text sits in each process's C buffer until exit
+    and would land BEHIND the JSON line: every rank flushes C stdio first, the ranks meet, the process group is torn
+    down (nothing prints after that), and only then does rank 0 print."""
+    import ctypes
+    sys.stdout.flush()
+    try:
+        ctypes.CDLL(None).fflush(None)
+    except Exception:
+        pass
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
     if rank == 0:
         print(json.dumps(result), flush=True)
-    if dist is not None:
-        dist.destroy_process_group()
 
 
 def kernel_sources_sha16():
@@ -483,11 +566,42 @@ def build_id_from_sources():
     return h.hexdigest()[:16]
 
 
+def _cpu_shard_worker(job):
+    """One process of the sharded CPU baseline: `threads` oneDNN threads, its own copy of the port, timed passes of
+    `sample` images between a common start barrier and `seconds` of wall time."""
+    backbone, hp, wpath, priors, sample, threads, seconds, barrier, seed = job
+    import numpy as np
+    import torch
+    torch.set_num_threads(threads)
+    from oracle import torch_cpu_graph as tg
+    from oracle import c_oracle as co
+    from utils import data_utils
+    with np.load(wpath) as z:
+        weights = {k: z[k] for k in z.files}
+    x = data_utils.synthetic_images(sample, hp["img_size"], seed=seed)
+
+    def one_pass():
+        d, p = tg.forward(backbone, hp, weights, x)
+        co.decode_nms(d, p, priors, hp["variances"])
+    one_pass()                                           # warm-up (oneDNN primitive creation)
+    barrier.wait(timeout=300)
+    t0 = time.perf_counter()
+    n = 0
+    while n == 0 or time.perf_counter() - t0 < seconds:
+        one_pass()
+        n += 1
+    return n * sample, t0, time.perf_counter()
+
+
 def cpu_baseline(backbone, hp, weights, priors, sample):
-    """The oracle's port timed on the host cores: torch-CPU (oneDNN) convs of the identical
-    graph + the plain-C decode/NMS restatement, on a bounded sample of the same workload.
-    `cores` = threads actually used (the fastest of a sweep on the full sample pass; oneDNN
-    over-subscribes badly on many-core hosts), `host_cores` = os.cpu_count()."""
+    """The oracle's port timed on the host cores: torch-CPU (oneDNN) convs of the identical graph + the plain-C
+    decode/NMS restatement, on a bounded sample of the same workload.  Two legs: (a) ONE process, the fastest thread
+    count of a sweep that stops at the first count that gets slower (oneDNN over-subscribes a many-core host: 0.15
+    img/s at 256 threads); (b) the same port SHARDED over processes -- P workers x that thread count, each on its own
+    images, common start -- which is how a CPU deployment would use such a host.  `value` is the better of the two,
+    `cores` the threads it used (P x T), `host_cores` = os.cpu_count()."""
+    import multiprocessing as mp
+    import tempfile
     import numpy as np
     import torch
     from oracle import torch_cpu_graph as tg
@@ -501,6 +615,7 @@ def cpu_baseline(backbone, hp, weights, priors, sample):
         co.decode_nms(d, p, priors, hp["variances"])
 
     sweep = {}
+    prev = 0.0
     for th in sorted({t for t in (4, 8, 16, 32, 64, ncpu) if t <= ncpu}):
         torch.set_num_threads(th)
         one_pass(x[:sample])                          # warm-up (oneDNN primitive creation)
@@ -510,8 +625,9 @@ def cpu_baseline(backbone, hp, weights, priors, sample):
             one_pass(x[:sample])
             dt = min(dt, time.perf_counter() - t0)
         sweep[th] = sample / dt
-        if dt > 20.0:                                 # hopeless thread count: stop climbing
+        if sweep[th] < prev:                          # the first thread count that gets slower ends the climb
             break
+        prev = sweep[th]
     threads = max(sweep, key=sweep.get)
     torch.set_num_threads(threads)
     t0 = time.perf_counter()
@@ -519,9 +635,10 @@ def cpu_baseline(backbone, hp, weights, priors, sample):
     while True:
         one_pass(x[:sample])
         passes += 1
-        if time.perf_counter() - t0 > 10.0 or passes >= 20:
+        if time.perf_counter() - t0 > 8.0 or passes >= 20:
             break
     dt = time.perf_counter() - t0
+    single = sample * passes / dt
 
     def rate(B, min_s, max_passes):
         one_pass(x[:B])
@@ -535,13 +652,41 @@ def cpu_baseline(backbone, hp, weights, priors, sample):
         return B * n / (time.perf_counter() - t1)
     b1 = rate(1, 3.0, 50)        # BASELINE configs[0]: batch 1
     b32 = rate(32, 4.0, 5)       # the reference's own batch_size (predictor.py:9)
-    return {"value": sample * passes / dt, "unit": "images/sec", "cores": threads, "threads": threads,
+
+    # (b) sharded over processes: P workers x T threads (T = the sweep's best, at most 8), P x T <= host cores
+    sharded = None
+    tsh = min(threads, 8)
+    procs = max(1, min(32, ncpu // tsh))
+    if procs > 1:
+        try:
+            ctx = mp.get_context("spawn")
+            with tempfile.TemporaryDirectory() as d:
+                wpath = os.path.join(d, "w.npz")
+                np.savez(wpath, **weights)
+                mgr = ctx.Manager()
+                barrier = mgr.Barrier(procs)
+                jobs = [(backbone, hp, wpath, priors, sample, tsh, 10.0, barrier, 100 + i) for i in range(procs)]
+                with ctx.Pool(procs) as pool:
+                    res = pool.map_async(_cpu_shard_worker, jobs).get(timeout=240)
+                mgr.shutdown()
+            imgs = sum(r[0] for r in res)
+            wall = max(r[2] for r in res) - min(r[1] for r in res)
+            sharded = {"images_per_sec": imgs / wall, "processes": procs, "threads_per_process": tsh,
+                       "seconds": wall, "images": imgs}
+        except Exception as exc:                        # a baseline, not the product: report and move on
+            sharded = {"error": repr(exc)[:200], "processes": procs, "threads_per_process": tsh}
+    best_sharded = sharded and sharded.get("images_per_sec", 0.0) > single
+    return {"value": sharded["images_per_sec"] if best_sharded else single, "unit": "images/sec",
+            "cores": procs * tsh if best_sharded else threads, "threads": threads,
             "host_cores": ncpu, "kind": "port",
+            "single_process_images_per_sec": single, "sharded": sharded,
             "images_per_sec_batch1": b1, "images_per_sec_batch32": b32,
             "thread_sweep_images_per_sec": {str(k): round(v, 2) for k, v in sweep.items()},
-            "sample": "%d passes of %d images at the fastest thread count of the sweep (torch-CPU oneDNN graph with "
-                      "TF padding + C decode/NMS oracle; TensorFlow itself is not installable here); batch-1 and "
-                      "batch-32 rates from 3-4 s samples each" % (passes, sample)}
+            "sample": "%s (torch-CPU oneDNN graph with TF padding + C decode/NMS oracle; TensorFlow itself is not installable "
+                      "here); single process: %d passes of %d images at the fastest thread count of a sweep that stops at the "
+                      "first slower count; batch-1 and batch-32 rates from 3-4 s samples each" % (
+                          ("%d processes x %d threads, ~10 s of passes of %d images each, common start" % (procs, tsh, sample))
+                          if best_sharded else "one process", passes, sample)}
 
 
 if __name__ == "__main__":

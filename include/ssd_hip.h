@@ -162,10 +162,12 @@ typedef struct ssd_conv_desc {
 int ssd_same_pads(int in, int k, int stride, int dilation, int* before, int* after);
 int ssd_conv_out_size(int in, int k, int stride, int dilation, int pad_before, int pad_after);
 
-/* Packed dense-conv weights: [Npad][Kpad] fp32, K = (ky*kw+kx)*Cin+ci, zero padded (device), followed by the
- * same matrix split EXACTLY into three bf16 planes [3][Npad][Kpad] (x = h + m + l; the "mfma3_*" tile configs run
- * every product as six bf16 MFMAs at fp32 accuracy, csrc/ssd_bf16x3.h).  ssd_conv_packed_weight_floats() covers
- * both.  scale/shift [Cout] are the folded BatchNorm (or 1/bias) epilogue vectors. */
+/* Packed dense-conv weights: [Npad][Kpad] fp32, K = (ky*kw+kx)*Cin+ci, zero padded (device), followed by four
+ * bf16 planes [4][Npad][Kpad] of the same matrix: h, m, l = its EXACT three-way split (x = h + m + l; the "mfma3_*"
+ * tile configs run every product as six bf16 MFMAs at fp32 accuracy, csrc/ssd_bf16x3.h) and r = its bf16 rounding
+ * (round to nearest even; the "bf16_*" tile configs of the net's precision-1 mode run ONE bf16 MFMA per product of
+ * once-rounded operands).  ssd_conv_packed_weight_floats() covers all of it.  scale/shift [Cout] are the folded
+ * BatchNorm (or 1/bias) epilogue vectors. */
 size_t ssd_conv_packed_weight_floats(int kh, int kw, int Cin, int Cout);
 int ssd_conv_pack_weights(const float* hwio_dev, int kh, int kw, int Cin, int Cout,
                           float* packed_dev, void* stream);
@@ -300,7 +302,13 @@ double ssd_net_layer_executed_flops(const ssd_net* net, int i, int B);
  * 0 disables it; "image_ticket" (default 0) makes that kernel combine its channel-group partial sums
  * inside the launch (arrival ticket, last arriver) instead of by a second launch; "overlap_heads" (default 1) runs the SSD head convs on side streams ("tail_on_side", default 0,
  * swaps the roles: big head convs on the caller's stream, the small tail layers on the side streams -- measured slower); "use_wino" (default 1)
- * offers the Winograd F(2x2,3x3) kernels to finalize's autotune for the 3x3 stride-1 convs. */
+ * offers the Winograd F(2x2,3x3) kernels to finalize's autotune for the 3x3 stride-1 convs;
+ * "precision" (default 0 = fp32, the reference's arithmetic: trainer.py:50-54 has no mixed precision; 1 = bf16, this
+ * build's extension for BASELINE.json configs[3] / [4]): every matrix operand of the dense / 1x1 convolutions is rounded
+ * once to bf16 (nearest even), each product is one bf16 MFMA with fp32 accumulation ("bf16_*" tiles, the bf16 forms of
+ * the row-band and whole-image block kernels); BatchNorm shifts, activations, residual adds, depthwise taps, softmax and
+ * the box math stay fp32, activations stay fp32 in HBM; the training step then runs its forward / backward-data convs
+ * on the bf16 tiles (fp32 master weights, weight gradients and Adam).  Takes effect at the next finalize. */
 int ssd_net_set_option(ssd_net* net, const char* name, int value);
 /* Diagnostics: per-phase mean cycles per wave of one fused block layer (clock64 inside the
  * kernel): prologue, expand, depthwise, project, weight staging, epilogue. */
@@ -349,6 +357,10 @@ int ssd_net_train_wait_bucket(ssd_net* net, int k, void* stream);
 int ssd_net_adam_step(ssd_net* net, const float* grads_flat_dev, float lr, float beta1, float beta2,
                       float eps, float grad_scale, void* stream);
 long ssd_net_train_steps(const ssd_net* net);
+/* Measurement: matrix-core FLOPs the last ssd_net_train_forward_backward issued, per instruction family --
+ * out3[0] conv forward + backward-data on fp32-MFMA tiles, out3[1] the same on split-bf16 tiles (six bf16 MFMAs per
+ * fp32 product), out3[2] weight gradients (fp32 MFMA).  bench.py --train prices each family at its own peak. */
+int ssd_net_train_matrix_flops(const ssd_net* net, double* out3);
 /* Sum of the layers' regularisation losses at the current weights: 5e-4 * sum(kernel^2) over VGG16's
  * backbone / extra convs (reference models/ssd_vgg16.py:44-45), 0 for MobileNetV2.  Keras adds this term to
  * the `loss` and `val_loss` that fit() logs and ModelCheckpoint(save_best_only) monitors (trainer.py:56-63).

@@ -138,6 +138,8 @@ def test_conv2d_all_configs(case):
     res = rng.standard_normal(ref.shape).astype(np.float32)
     ran = 0
     for cfg in range(-1, lib.ssd_conv_num_configs()):
+        if cfg >= 0 and lib.ssd_conv_config_name(cfg).startswith(b"bf16_"):
+            continue            # the bf16 (one-product) tiles have their own tolerance: tests/test_bf16_gpu.py
         rc, out = run_conv(x, w, scale, shift, res, stride, dil, pads, act=2, cfg=cfg)
         if rc == -3 and cfg >= 0:
             continue            # this tile config cannot take the shape (documented constraint)
@@ -542,6 +544,8 @@ def test_conv2d_every_config_and_split_on_net_shapes(H, Cin, Cout, k, stride):
     ref = no.relu(no.conv2d(x, w, bias, stride, 1, "same" if k == 3 else "valid"))
     ran = 0
     for cfg in range(lib.ssd_conv_num_configs()):
+        if lib.ssd_conv_config_name(cfg).startswith(b"bf16_"):
+            continue            # (tests/test_bf16_gpu.py)
         for split in (1, 2, 4, 8, 16):
             rc, out = run_conv(x, w, None, bias, None, stride, 1, pads, act=1, cfg=cfg, split_k=split)
             if rc == -3:

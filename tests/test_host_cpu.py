@@ -40,7 +40,7 @@ def test_pure_host_entry_points():
     assert l.ssd_same_pads(10, 3, 2, 1, ctypes.byref(b), ctypes.byref(a)) == 5 and (b.value, a.value) == (0, 1)
     assert l.ssd_same_pads(19, 3, 1, 6, ctypes.byref(b), ctypes.byref(a)) == 19 and (b.value, a.value) == (6, 6)
     assert l.ssd_conv_out_size(5, 3, 1, 1, 0, 0) == 3 and l.ssd_conv_out_size(5, 3, 0, 1, 0, 0) == 0
-    assert l.ssd_conv_packed_weight_floats(3, 3, 576, 84) == 5184 * 96 * 5 // 2      # fp32 [Npad][Kpad] + its three bf16 planes
+    assert l.ssd_conv_packed_weight_floats(3, 3, 576, 84) == 5184 * 96 * 3      # fp32 [Npad][Kpad] + its four bf16 planes (h, m, l, r)
     fm = (ctypes.c_int * 6)(19, 10, 5, 3, 2, 1)
     na = (ctypes.c_int * 6)(3, 5, 5, 5, 3, 3)
     assert l.ssd_priors_count(fm, na, 6) == 2268

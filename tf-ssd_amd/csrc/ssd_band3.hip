@@ -38,6 +38,7 @@ __global__ __launch_bounds__(256) void split3_we_kernel(const float* __restrict_
         out[e] = h;
         out[total + e] = m;
         out[2 * total + e] = l;
+        out[3 * total + e] = rne1(v);        // plane 3: the bf16 rounding (precision-1 form of the kernel)
     }
 }
 // out[plane][row][pair][g4][8]: Wp (packed [npad][kpad], K = Ce) split, k-slots in chunk-pair order
@@ -55,11 +56,16 @@ __global__ __launch_bounds__(256) void split3_wp_kernel(const float* __restrict_
         out[e] = h;
         out[total + e] = m;
         out[2 * total + e] = l;
+        out[3 * total + e] = rne1(v);
     }
 }
 
-template <int CIN, int NT, int T, int TO, int S, int P>
+// NP = 3: fp32 results through the exact three-way split (six MFMAs per product); NP = 1: the net's bf16 mode (operands
+// rounded once, one MFMA per product, plane 3 of the packed weights) -- a third of the plane registers, so blocks 1-2
+// (T = 9 / 8 tiles per wave) fit as well
+template <int CIN, int NT, int T, int TO, int S, int P, int NP>
 __global__ __launch_bounds__(kB3Threads) void mbv2_band3_block_kernel(const FusedBlockParams p) {
+    constexpr int WPL = NP == 1 ? 3 : 0;
     static_assert(P % 8 == 0 && CIN <= 32 && CIN % 8 == 0, "");
     constexpr int NE = b3_ne(T);
     constexpr int EBUF = NE * kB3C * 4;
@@ -93,7 +99,7 @@ __global__ __launch_bounds__(kB3Threads) void mbv2_band3_block_kernel(const Fuse
     if (tid < 64) *reinterpret_cast<f32x4*>(Es + (tid >> 5) * EBUF + (tid & 31) * 16) = f32x4{0.f, 0.f, 0.f, 0.f};
 
     // ---- the wave's input tiles: X split once into three bf16 planes (lane = pixel x channels g4*8 .. g4*8 + 7)
-    B3 xs[T];
+    BP<NP> xs[T];
     unsigned realm = 0;
 #pragma unroll
     for (int t = 0; t < T; ++t) {
@@ -107,7 +113,7 @@ __global__ __launch_bounds__(kB3Threads) void mbv2_band3_block_kernel(const Fuse
         const float* xp = p.x + (((long)img * H + (real ? ri : 0)) * W + (real ? c : 0)) * CIN + (g4 * 8 < CIN ? g4 * 8 : 0);
         const f32x4 a = have ? *reinterpret_cast<const f32x4*>(xp) : f32x4{0.f, 0.f, 0.f, 0.f};
         const f32x4 b = have ? *reinterpret_cast<const f32x4*>(xp + 4) : f32x4{0.f, 0.f, 0.f, 0.f};
-        xs[t] = split3(a, b);
+        xs[t] = splitN<NP>(a, b);
     }
     const int ew = (8 + wave * 16 + l15) * 64 + ((g4 ^ ((l15 >> 1) & 3)) << 4);
 
@@ -129,33 +135,31 @@ __global__ __launch_bounds__(kB3Threads) void mbv2_band3_block_kernel(const Fuse
     }
 
     auto load_we = [&](int j) {
-        B3 w;
-        const short* base = p.we3 + ((long)(j * kB3C + l15) * 32 + g4 * 8);
-        w.h = *reinterpret_cast<const bf16x8*>(base);
-        w.m = *reinterpret_cast<const bf16x8*>(base + plane_e);
-        w.l = *reinterpret_cast<const bf16x8*>(base + 2 * plane_e);
+        BP<NP> w;
+        const short* base = p.we3 + WPL * plane_e + ((long)(j * kB3C + l15) * 32 + g4 * 8);
+#pragma unroll
+        for (int pl = 0; pl < NP; ++pl) w.p[pl] = *reinterpret_cast<const bf16x8*>(base + pl * plane_e);
         return w;
     };
-    auto load_wp = [&](B3 (&w)[NT], int pair) {
+    auto load_wp = [&](BP<NP> (&w)[NT], int pair) {
 #pragma unroll
         for (int ni = 0; ni < NT; ++ni) {
-            const short* base = p.wp3 + ((((long)(ni * 16 + l15) * npairs + pair) * 4 + g4) * 8);
-            w[ni].h = *reinterpret_cast<const bf16x8*>(base);
-            w[ni].m = *reinterpret_cast<const bf16x8*>(base + plane_p);
-            w[ni].l = *reinterpret_cast<const bf16x8*>(base + 2 * plane_p);
+            const short* base = p.wp3 + WPL * plane_p + ((((long)(ni * 16 + l15) * npairs + pair) * 4 + g4) * 8);
+#pragma unroll
+            for (int pl = 0; pl < NP; ++pl) w[ni].p[pl] = *reinterpret_cast<const bf16x8*>(base + pl * plane_p);
         }
     };
     __syncthreads();
 
-    auto expand = [&](int j, const B3& wa) {
+    auto expand = [&](int j, const BP<NP>& wa) {
         const f32x4 sh = *reinterpret_cast<const f32x4*>(Ps + j * kB3C + g4 * 4);
         char* eb = Es + (j & 1) * EBUF + ew;
 #pragma unroll
         for (int t0 = 0; t0 < T; t0 += 2) {
             if (t0 >= nti) break;
             const int t1 = t0 + 1 < T ? t0 + 1 : t0;
-            f32x4 a0 = mma6(wa, xs[t0], sh), a1 = sh;
-            if (t0 + 1 < T) a1 = mma6(wa, xs[t1], sh);
+            f32x4 a0 = mmaN<NP>(wa, xs[t0], sh), a1 = sh;
+            if (t0 + 1 < T) a1 = mmaN<NP>(wa, xs[t1], sh);
             const float hi0 = (realm >> t0) & 1u ? 6.0f : 0.0f;
 #pragma unroll
             for (int e = 0; e < 4; ++e) a0[e] = __builtin_amdgcn_fmed3f(a0[e], 0.0f, hi0);
@@ -178,14 +182,14 @@ __global__ __launch_bounds__(kB3Threads) void mbv2_band3_block_kernel(const Fuse
         for (int ni = 0; ni < NT; ++ni) acc[t][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
 
-    B3 wa = load_we(0);
+    BP<NP> wa = load_we(0);
     expand(0, wa);
     if (nchunk > 1) wa = load_we(1);
 
     for (int i = 0; i < nchunk; ++i) {
         b3_lds_barrier();           // E(i) is complete; everyone is done reading E(i - 1)
         const bool flush = (i & 1) || i + 1 == nchunk;      // the project runs after every second chunk (and after a last odd one)
-        B3 wp[NT];
+        BP<NP> wp[NT];
         if (flush) load_wp(wp, i >> 1);                     // in flight across the depthwise
         const char* eb = Es + (i & 1) * EBUF;
         f32x4 w[9];
@@ -206,9 +210,9 @@ __global__ __launch_bounds__(kB3Threads) void mbv2_band3_block_kernel(const Fuse
             if (!flush) {
                 dprev[t] = d;
             } else {
-                const B3 ds = (i & 1) ? split3(dprev[t], d) : split3(d, f32x4{0.f, 0.f, 0.f, 0.f});
+                const BP<NP> ds = (i & 1) ? splitN<NP>(dprev[t], d) : splitN<NP>(d, f32x4{0.f, 0.f, 0.f, 0.f});
 #pragma unroll
-                for (int ni = 0; ni < NT; ++ni) acc[t][ni] = mma6(wp[ni], ds, acc[t][ni]);
+                for (int ni = 0; ni < NT; ++ni) acc[t][ni] = mmaN<NP>(wp[ni], ds, acc[t][ni]);
             }
         }
         if (i + 1 < nchunk) {
@@ -235,10 +239,15 @@ __global__ __launch_bounds__(kB3Threads) void mbv2_band3_block_kernel(const Fuse
 typedef void (*band3_kernel_t)(const FusedBlockParams);
 struct Band3Cfg {
     int cin, nt, t, to, stride, pitch;
-    band3_kernel_t fn;
+    band3_kernel_t fn;          // split-bf16 (fp32 results); nullptr: the shape only exists in the bf16 form
+    band3_kernel_t fn1;         // bf16 (precision 1)
 };
-#define B3CFG(CIN, NT, T, TO, S, P) {CIN, NT, T, TO, S, P, mbv2_band3_block_kernel<CIN, NT, T, TO, S, P>}
+#define B3CFG(CIN, NT, T, TO, S, P) {CIN, NT, T, TO, S, P, mbv2_band3_block_kernel<CIN, NT, T, TO, S, P, 3>, mbv2_band3_block_kernel<CIN, NT, T, TO, S, P, 1>}
+#define B1CFG(CIN, NT, T, TO, S, P) {CIN, NT, T, TO, S, P, nullptr, mbv2_band3_block_kernel<CIN, NT, T, TO, S, P, 1>}
 const Band3Cfg kBand3[] = {
+    B1CFG(16, 2, 9, 2, 2, 152),   // bf16 form only: block 1 (16 -> 96 -> 24, 150x150 -> 75x75) and block 2 (75x75), the
+    B1CFG(24, 2, 8, 6, 1, 80),    // fp32 band kernel's shapes
+    B1CFG(24, 2, 8, 6, 1, 136),   // block 2 of the 512x512 graph
     // blocks 1-2 (Cin 16 / 24, T = 9 / 6 tiles per wave) stay on the fp32 band kernel: the three split X planes cost
     // 12 registers per tile, the kernel spilled (9 / 46 registers) and measured 149-158 / 162-172 us against 143 / 105
     B3CFG(24, 2, 7, 2, 2, 80),    // block 3
@@ -257,7 +266,7 @@ int band3_max_rows(const Band3Cfg& c, const FusedBlockParams& p) {
     return r;
 }
 
-const Band3Cfg* pick_band3(const FusedBlockParams& p) {
+const Band3Cfg* pick_band3(const FusedBlockParams& p, bool bf16) {
     if (p.Ce % kB3C != 0 || p.Cout % 8 != 0 || p.Cin > 32) return nullptr;
     if (p.stride == 1 && (p.H != p.Ho || p.W != p.Wo || p.pad_t != 1 || p.pad_l != 1)) return nullptr;
     if (p.stride == 2 && (p.residual || p.Ho != (p.H + 1) / 2 || p.Wo != (p.W + 1) / 2 || p.pad_t > 1 || p.pad_l > 1 ||
@@ -267,6 +276,7 @@ const Band3Cfg* pick_band3(const FusedBlockParams& p) {
     if (p.e_out) return nullptr;
     for (const auto& c : kBand3) {
         if (c.cin != p.Cin || c.stride != p.stride || (p.Cout + 15) / 16 != c.nt || p.npad_p < c.nt * 16) continue;
+        if (!bf16 && !c.fn) continue;
         if (p.W + 1 > c.pitch || p.W + 8 < c.pitch) continue;
         if (p.stride == 2 && 2 * (p.Wo - 1) - p.pad_l + 2 >= c.pitch) continue;
         if (band3_max_rows(c, p) < 1) continue;
@@ -282,13 +292,13 @@ size_t band3_lds_bytes(const Band3Cfg& c, const FusedBlockParams& p) {
 }  // namespace
 
 bool band3_block_supported(const FusedBlockParams& p) {
-    const Band3Cfg* c = pick_band3(p);
+    const Band3Cfg* c = pick_band3(p, p.bf16 != 0);
     return c && band3_lds_bytes(*c, p) <= 160 * 1024;
 }
 
 // bf16 planes of the two 1x1 weight matrices (shorts): sizes and the packing launches (run at finalize)
-size_t band3_we_shorts(int Ce) { return (size_t)3 * Ce * 32; }
-size_t band3_wp_shorts(int npad_p, int Ce) { return (size_t)3 * npad_p * (((Ce / kB3C) + 1) / 2) * 32; }
+size_t band3_we_shorts(int Ce) { return (size_t)4 * Ce * 32; }
+size_t band3_wp_shorts(int npad_p, int Ce) { return (size_t)4 * npad_p * (((Ce / kB3C) + 1) / 2) * 32; }
 int launch_band3_pack(const float* we, int Ce, int Cin, int kpad_e, short* we3, const float* wp, int npad_p, int kpad_p,
                       short* wp3, hipStream_t st) {
     const int npairs = ((Ce / kB3C) + 1) / 2;
@@ -300,7 +310,7 @@ int launch_band3_pack(const float* we, int Ce, int Cin, int kpad_e, short* we3, 
 }
 
 int launch_band3_block(FusedBlockParams p, hipStream_t st) {
-    const Band3Cfg* c = pick_band3(p);
+    const Band3Cfg* c = pick_band3(p, p.bf16 != 0);
     if (!c || !p.we3 || !p.wp3) {
         set_error("band3 block: unsupported shape Cin=%d Ce=%d Cout=%d %dx%d stride=%d (or weights not split)", p.Cin, p.Ce, p.Cout,
                   p.H, p.W, p.stride);
@@ -311,9 +321,10 @@ int launch_band3_block(FusedBlockParams p, hipStream_t st) {
     p.bands = (p.Ho + rmax - 1) / rmax;
     const size_t lds = band3_lds_bytes(*c, p);
     SSD_UNSUPPORTED_IF(lds > 160 * 1024, "band3 block: needs %zu B of LDS", lds);
+    const band3_kernel_t fn = p.bf16 ? c->fn1 : c->fn;
     if (lds > 64 * 1024)
-        SSD_HIP(hipFuncSetAttribute((const void*)c->fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(c->fn, dim3((unsigned)((long)p.B * p.bands)), dim3(kB3Threads), lds, st, p);
+        SSD_HIP(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(fn, dim3((unsigned)((long)p.B * p.bands)), dim3(kB3Threads), lds, st, p);
     SSD_LAUNCH_CHECK();
     return SSD_OK;
 }

@@ -68,4 +68,53 @@ __device__ __forceinline__ b3_f32x4 mma6(const B3& w, const B3& x, b3_f32x4 acc)
     return acc;
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// Precision-generic forms: NP = 3 the exact three-way split above (fp32 results), NP = 1 the "bf16" mode of the net
+// (option "precision" 1; BASELINE.json configs[3] / [4]): every matrix operand is rounded ONCE to bf16 (round to
+// nearest even, v_cvt_pk_bf16_f32) and every product is ONE v_mfma_f32_16x16x32_bf16 with fp32 accumulation -- the
+// standard mixed-precision contraction, 1/6 of the split form's matrix work.  Epilogues (BatchNorm shift, ReLU6,
+// residual adds), the depthwise taps, softmax and the box math stay fp32 in either mode.
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef float b3_f32x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ unsigned rne2(float a, float b) {          // two fp32 -> packed bf16 pair (a in the low half)
+    const bf16x2_t r = __builtin_convertvector(b3_f32x2{a, b}, bf16x2_t);
+    return __builtin_bit_cast(unsigned, r);
+}
+__device__ __forceinline__ short rne1(float a) { return (short)(rne2(a, 0.f) & 0xffffu); }
+__device__ __forceinline__ uint2 rne4(const b3_f32x4 v) { return make_uint2(rne2(v[0], v[1]), rne2(v[2], v[3])); }
+
+template <int NP>
+struct BP {
+    bf16x8 p[NP];          // NP = 3: h, m, l;  NP = 1: the bf16 rounding
+};
+template <int NP>
+__device__ __forceinline__ BP<NP> splitN(const b3_f32x4 a, const b3_f32x4 b) {
+    BP<NP> r;
+    if constexpr (NP == 3) {
+        const B3 s = split3(a, b);
+        r.p[0] = s.h; r.p[1] = s.m; r.p[2] = s.l;
+    } else {
+        const uint4 u = make_uint4(rne2(a[0], a[1]), rne2(a[2], a[3]), rne2(b[0], b[1]), rne2(b[2], b[3]));
+        r.p[0] = __builtin_bit_cast(bf16x8, u);
+    }
+    return r;
+}
+template <int NP>
+__device__ __forceinline__ b3_f32x4 mmaN(const BP<NP>& w, const BP<NP>& x, b3_f32x4 acc) {
+    if constexpr (NP == 3) {
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w.p[1], x.p[1], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w.p[0], x.p[2], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w.p[2], x.p[0], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w.p[0], x.p[1], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w.p[1], x.p[0], acc, 0, 0, 0);
+    }
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(w.p[0], x.p[0], acc, 0, 0, 0);
+}
+// weight planes at pack time: NP = 3 the exact split, NP = 1 plane 0 = the bf16 rounding (planes 1, 2 unused: zero)
+__device__ __forceinline__ void pack_planes(float x, int bf16_mode, short& h, short& m, short& l) {
+    if (bf16_mode) { h = rne1(x); m = 0; l = 0; }
+    else split1(x, h, m, l);
+}
+
 }  // namespace ssd

@@ -10,7 +10,7 @@ namespace ssd {
 struct ConvParams {
     const float* in;
     const float* w;        // packed [Npad][Kpad]
-    const short* w3;       // the same split exactly into three bf16 planes [3][Npad][Kpad] (ssd_conv3.hip) or nullptr
+    const short* w3;       // the same as four bf16 planes [4][Npad][Kpad]: the exact split h, m, l and the bf16 rounding r (ssd_conv3.hip) or nullptr
     const float* scale;    // [Cout] or nullptr (== 1)
     const float* shift;    // [Cout] or nullptr (== 0)
     const float* residual; // dense [M][Cout] or nullptr
@@ -31,7 +31,12 @@ struct ConvParams {
     int split_k;           // >1: partial sums to `partial` [split][M][Cout], epilogue deferred
     float* partial;
     const float* wino_w;   // Winograd F(2x2,3x3) weights U [16][Npad][Cin] (ssd_wino.hip) or nullptr
+    int bf16;              // the net's precision-1 mode: the cost model (conv_pick_config) may take the bf16 tiles
 };
+// may a net of this precision (0 fp32, 1 bf16) choose config `cfg`?  fp32 nets never take the bf16 (one-product) tiles;
+// bf16 nets take them instead of the split-bf16 / Winograd tiles (the fp32-MFMA and skinny tiles serve the small tail layers
+// in both modes: more accurate than asked for)
+bool conv_config_allowed(int cfg, int precision);
 
 // One fused MobileNetV2 inverted-residual block (csrc/ssd_fused.hip).
 struct FusedBlockParams {
@@ -48,9 +53,10 @@ struct FusedBlockParams {
     int kpad_e, kpad_p, npad_p;
     int tiles_y, tiles_x;       // filled by the launcher
     // whole-image kernel (csrc/ssd_imgblock.hip): expanded-channel groups per image and their meeting point
+    int bf16;                   // the net's precision-1 mode: bf16 forms of the band / whole-image kernels (operands rounded once to bf16, one MFMA per product)
     int groups;                 // G >= 1 (filled by the caller from image_block_groups)
-    const short* we3;           // split-bf16 band kernel (csrc/ssd_band3.hip): bf16 planes of we [3][Ce][32] ...
-    const short* wp3;           // ... and of wp [3][npad_p][pairs][4][8]
+    const short* we3;           // split-bf16 band kernel (csrc/ssd_band3.hip): bf16 planes of we [4][Ce][32] (h, m, l, r) ...
+    const short* wp3;           // ... and of wp [4][npad_p][pairs][4][8]
     int bands;                  // row-band kernel (csrc/ssd_bandblock.hip): bands per image (filled by the launcher)
     float* slabs;               // [G][B][Ho*Wo][Cout] partial sums (G > 1)
     unsigned* tickets;          // [B] arrival counters, zero between launches
@@ -150,7 +156,8 @@ bool mfma3_config_valid(int i, const ConvParams& p);
 long mfma3_grid_blocks(int i, const ConvParams& p);
 int mfma3_k_tiles(const ConvParams& p);
 void mfma3_tile(int i, int* BM, int* BN);
-int mfma3_launch(const ConvParams& p, int i, hipStream_t st);
+int mfma3_launch(const ConvParams& p, int i, hipStream_t st, bool bf16 = false);
+const char* bf16_config_name(int i);     // bf16 (one-product) form of split-bf16 tile i; config ids behind the mfma3 ones
 
 int launch_dwconv3x3(const float* in, int B, int H, int W, int C, int stride, int pad_t, int pad_l,
                      int Ho, int Wo, const float* w, const float* scale, const float* shift, int act,
@@ -160,10 +167,10 @@ int launch_maxpool(const float* in, int B, int H, int W, int C, int k, int strid
 int launch_l2norm(const float* in, long pixels, int C, const float* gamma, float* out, hipStream_t st);
 int launch_softmax(const float* in, long rows, int L, float* out, hipStream_t st);
 int launch_pack_weights(const float* hwio, int K, int Cout, int Kpad, int Npad, float* packed, hipStream_t st);
-// packed fp32 weights + room for their three bf16 planes (conv_split_planes points at them)
+// packed fp32 weights + room for their four bf16 planes (conv_split_planes points at them)
 inline size_t conv_packed_floats(int K, int Cout) {
     const size_t n = (size_t)conv_kpad(K) * conv_npad(Cout);
-    return n + (3 * n + 1) / 2;
+    return n + 2 * n;
 }
 inline const short* conv_split_planes(const float* packed, int K, int Cout) {
     return reinterpret_cast<const short*>(packed + (size_t)conv_kpad(K) * conv_npad(Cout));

@@ -283,20 +283,31 @@ constexpr int kNumMfmaCfgs = sizeof(kCfgs) / sizeof(kCfgs[0]);
 // then the split-bf16 implicit-GEMM tiles (csrc/ssd_conv3.hip)
 static int skinny_cfg0() { return kNumMfmaCfgs + wino_num_configs(); }
 static int mfma3_cfg0() { return kNumMfmaCfgs + wino_num_configs() + skinny_num_configs(); }
-static int direct_cfg() { return kNumMfmaCfgs + wino_num_configs() + skinny_num_configs() + mfma3_num_configs(); }
+// then the same tiles as bf16 (one-product) kernels: only chosen when asked for by name / by the net's precision-1 mode
+static int bf16_cfg0() { return kNumMfmaCfgs + wino_num_configs() + skinny_num_configs() + mfma3_num_configs(); }
+static int direct_cfg() { return kNumMfmaCfgs + wino_num_configs() + skinny_num_configs() + 2 * mfma3_num_configs(); }
 #define kSkinnyCfg0 skinny_cfg0()
 #define kMfma3Cfg0 mfma3_cfg0()
+#define kBf16Cfg0 bf16_cfg0()
 #define kDirectCfg direct_cfg()
 
 int conv_num_mfma_configs() { return kNumMfmaCfgs; }
 int conv_num_configs() { return kDirectCfg + 1; }
 const char* conv_config_name(int cfg) {
     if (cfg == kDirectCfg) return "direct_valu";
-    if (cfg >= kMfma3Cfg0 && cfg < kDirectCfg) return mfma3_config_name(cfg - kMfma3Cfg0);
+    if (cfg >= kBf16Cfg0 && cfg < kDirectCfg) return bf16_config_name(cfg - kBf16Cfg0);
+    if (cfg >= kMfma3Cfg0 && cfg < kBf16Cfg0) return mfma3_config_name(cfg - kMfma3Cfg0);
     if (cfg >= kSkinnyCfg0 && cfg < kMfma3Cfg0) return skinny_config_name(cfg - kSkinnyCfg0);
     if (cfg >= kNumMfmaCfgs && cfg < kSkinnyCfg0) return wino_config_name(cfg - kNumMfmaCfgs);
     if (cfg < 0 || cfg >= kNumMfmaCfgs) return "?";
     return kCfgs[cfg].name;
+}
+
+bool conv_config_allowed(int cfg, int precision) {
+    const bool bf16 = cfg >= kBf16Cfg0 && cfg < kDirectCfg;
+    if (!precision) return !bf16;
+    const bool split = cfg >= kMfma3Cfg0 && cfg < kBf16Cfg0, wino = cfg >= kNumMfmaCfgs && cfg < kSkinnyCfg0;
+    return !split && !wino;
 }
 
 static bool is_gemm1x1(const ConvParams& p) {
@@ -305,7 +316,8 @@ static bool is_gemm1x1(const ConvParams& p) {
 
 bool conv_config_valid(int cfg, const ConvParams& p) {
     if (cfg == kDirectCfg) return (size_t)p.K * ((p.Cout + 3) & ~3) * 4 <= 64 * 1024;
-    if (cfg >= kMfma3Cfg0 && cfg < kDirectCfg) return mfma3_config_valid(cfg - kMfma3Cfg0, p);
+    if (cfg >= kBf16Cfg0 && cfg < kDirectCfg) return mfma3_config_valid(cfg - kBf16Cfg0, p);
+    if (cfg >= kMfma3Cfg0 && cfg < kBf16Cfg0) return mfma3_config_valid(cfg - kMfma3Cfg0, p);
     if (cfg >= kSkinnyCfg0 && cfg < kMfma3Cfg0) return skinny_config_valid(cfg - kSkinnyCfg0, p);
     if (cfg >= kNumMfmaCfgs && cfg < kSkinnyCfg0) return wino_config_valid(cfg - kNumMfmaCfgs, p);
     if (cfg < 0 || cfg >= kNumMfmaCfgs) return false;
@@ -337,6 +349,7 @@ int conv_pick_config(const ConvParams& p) {
     }
     // split-bf16 tiles (need the weights' planes): matrix rate derated to what the kernels measured (the staging of
     // the split operands shares the loop), 6 bytes per weight element; not for the smallest problems
+    // (bf16 mode: the same tiles with one product instead of six -- matrix rate x 4 in the model, 2 bytes per weight element)
     if (p.w3 && p.M >= 2048 && p.K >= 64) {
         for (int c = 0; c < mfma3_num_configs(); ++c) {
             if (!mfma3_config_valid(c, p)) continue;
@@ -345,11 +358,11 @@ int conv_pick_config(const ConvParams& p) {
             const double mb = (double)((p.M + BM - 1) / BM), nb = (double)((p.Cout + BN - 1) / BN);
             const double kk = (double)round_up(p.K, 32);
             const double waves = ceil(mb * nb / 256.0);
-            const double t_mfma = waves * (double)BM * BN * kk * 2.0 / (260e12 / 256.0);
-            const double bytes = mb * BM * kk * nb * 4.0 + nb * BN * kk * mb * 6.0 + (double)p.M * p.Cout * 4.0;
+            const double t_mfma = waves * (double)BM * BN * kk * 2.0 / ((p.bf16 ? 1000e12 : 260e12) / 256.0);
+            const double bytes = mb * BM * kk * nb * 4.0 + nb * BN * kk * mb * (p.bf16 ? 2.0 : 6.0) + (double)p.M * p.Cout * 4.0;
             const double t_mem = bytes / 6.0e12;
             const double cost = (t_mfma > t_mem ? t_mfma : t_mem) + 0.25 * (t_mfma < t_mem ? t_mfma : t_mem);
-            if (cost < best_cost) { best_cost = cost; best = kMfma3Cfg0 + c; }
+            if (cost < best_cost) { best_cost = cost; best = (p.bf16 ? kBf16Cfg0 : kMfma3Cfg0) + c; }
         }
     }
     if (best < 0 && conv_config_valid(kDirectCfg, p)) best = kDirectCfg;
@@ -357,7 +370,8 @@ int conv_pick_config(const ConvParams& p) {
 }
 
 long conv_grid_blocks(int cfg, const ConvParams& p) {
-    if (cfg >= kMfma3Cfg0 && cfg < kDirectCfg) return mfma3_grid_blocks(cfg - kMfma3Cfg0, p);
+    if (cfg >= kBf16Cfg0 && cfg < kDirectCfg) return mfma3_grid_blocks(cfg - kBf16Cfg0, p);
+    if (cfg >= kMfma3Cfg0 && cfg < kBf16Cfg0) return mfma3_grid_blocks(cfg - kMfma3Cfg0, p);
     if (cfg >= kSkinnyCfg0 && cfg < kMfma3Cfg0) return skinny_grid_blocks(cfg - kSkinnyCfg0, p);
     if (cfg >= kNumMfmaCfgs && cfg < kSkinnyCfg0) return wino_grid_blocks(cfg - kNumMfmaCfgs, p);
     if (cfg < 0 || cfg >= kNumMfmaCfgs) return 0;
@@ -365,7 +379,7 @@ long conv_grid_blocks(int cfg, const ConvParams& p) {
     return ((p.M + g.BM - 1) / g.BM) * ((p.Cout + g.BN - 1) / g.BN);
 }
 int conv_k_tiles(int cfg, const ConvParams& p) {
-    if (cfg >= kMfma3Cfg0 && cfg < kDirectCfg) return mfma3_k_tiles(p);
+    if (cfg >= kMfma3Cfg0 && cfg < kDirectCfg) return mfma3_k_tiles(p);      // (split-bf16 and bf16 tiles)
     if (cfg >= kSkinnyCfg0 && cfg < kMfma3Cfg0) return p.K / 16;
     if (cfg >= kNumMfmaCfgs && cfg < kSkinnyCfg0) return wino_k_tiles(p);
     if (cfg < 0 || cfg >= kNumMfmaCfgs) return 0;
@@ -384,7 +398,8 @@ int conv_launch(const ConvParams& p, int cfg, hipStream_t st) {
         return SSD_E_UNSUPPORTED;
     }
     if (cfg >= kMfma3Cfg0 && cfg < kDirectCfg) {
-        const int rc = mfma3_launch(p, cfg - kMfma3Cfg0, st);
+        const bool bf16 = cfg >= kBf16Cfg0;
+        const int rc = mfma3_launch(p, cfg - (bf16 ? kBf16Cfg0 : kMfma3Cfg0), st, bf16);
         if (rc || p.split_k <= 1) return rc;
         return launch_splitk_reduce(p, st);
     }

@@ -16,10 +16,13 @@ struct Conv3Cfg {
     const char* name;
     int BM, BN, threads;
     conv3_kernel_t gemm, general;
+    const char* name1;                  // the same tile as a bf16 (one-product) kernel: the net's precision-1 mode
+    conv3_kernel_t gemm1, general1;
 };
 #define C3CFG(MT, NT, WM, WN)                                                           \
     {"mfma3_" #MT "x" #NT "_" #WM "x" #WN, 16 * MT * WM, 16 * NT * WN, 64 * WM * WN,      \
-     conv_mfma3_kernel<MT, NT, WM, WN, true>, conv_mfma3_kernel<MT, NT, WM, WN, false>}
+     conv_mfma3_kernel<MT, NT, WM, WN, true>, conv_mfma3_kernel<MT, NT, WM, WN, false>,  \
+     "bf16_" #MT "x" #NT "_" #WM "x" #WN, conv_bf16_kernel<MT, NT, WM, WN, true>, conv_bf16_kernel<MT, NT, WM, WN, false>}
 const Conv3Cfg kCfg3[] = {
     C3CFG(4, 4, 2, 2),    // 128 x 128
     C3CFG(2, 4, 2, 2),    // 64 x 128
@@ -42,8 +45,10 @@ const Conv3Cfg kCfg3[] = {
     C3CFG(4, 5, 4, 2),    // 256 x 160
 };
 constexpr int kNumCfg3 = sizeof(kCfg3) / sizeof(kCfg3[0]);
-int c3_lds_bytes(const Conv3Cfg& g) { return 2 * 3 * (g.BM + g.BN) * 64; }
+int c3_lds_bytes(const Conv3Cfg& g, int planes) { return 2 * planes * (g.BM + g.BN) * 64; }
 
+// four bf16 planes behind the packed fp32 weights: h, m, l (the exact split, x = h + m + l) and r = the bf16 rounding of
+// x (round to nearest even) for the one-product bf16 kernels
 __global__ __launch_bounds__(256) void pack_split_kernel(const float* __restrict__ w, const long total, short* __restrict__ out) {
     for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
         short h, m, l;
@@ -51,6 +56,7 @@ __global__ __launch_bounds__(256) void pack_split_kernel(const float* __restrict
         out[e] = h;
         out[total + e] = m;
         out[2 * total + e] = l;
+        out[3 * total + e] = rne1(w[e]);
     }
 }
 
@@ -81,16 +87,19 @@ void mfma3_tile(int i, int* BM, int* BN) {
     *BN = (i >= 0 && i < kNumCfg3) ? kCfg3[i].BN : 0;
 }
 
-// the kernel only (the caller adds the split-K reduction)
-int mfma3_launch(const ConvParams& p, int i, hipStream_t st) {
+const char* bf16_config_name(int i) { return (i >= 0 && i < kNumCfg3) ? kCfg3[i].name1 : "?"; }
+
+// the kernel only (the caller adds the split-K reduction); bf16: the one-product form of the same tile
+int mfma3_launch(const ConvParams& p, int i, hipStream_t st, bool bf16) {
     if (!mfma3_config_valid(i, p)) {
-        set_error("conv2d: split-bf16 config %d cannot run Cin=%d k=%dx%d", i, p.Cin, p.kh, p.kw);
+        set_error("conv2d: split-bf16 / bf16 config %d cannot run Cin=%d k=%dx%d", i, p.Cin, p.kh, p.kw);
         return SSD_E_UNSUPPORTED;
     }
     const long blocks = mfma3_grid_blocks(i, p);
     SSD_UNSUPPORTED_IF(blocks > 0x7fffffffL, "conv2d: grid too large");
-    const conv3_kernel_t fn = c3_gemm1x1(p) ? kCfg3[i].gemm : kCfg3[i].general;
-    const int lds = c3_lds_bytes(kCfg3[i]);
+    const conv3_kernel_t fn = bf16 ? (c3_gemm1x1(p) ? kCfg3[i].gemm1 : kCfg3[i].general1)
+                                   : (c3_gemm1x1(p) ? kCfg3[i].gemm : kCfg3[i].general);
+    const int lds = c3_lds_bytes(kCfg3[i], bf16 ? 1 : 3);
     if (lds > 64 * 1024) SSD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     dim3 grid((unsigned)blocks, p.split_k > 1 ? p.split_k : 1);
     hipLaunchKernelGGL(fn, grid, dim3(kCfg3[i].threads), lds, st, p);

@@ -24,10 +24,14 @@ __device__ __forceinline__ float apply_act(float v, int act) {
 #define SSD_CONV_ABLATE 0
 #endif
 
-template <int MT, int NT, int WM, int WN, int BK, bool GEMM1X1, bool SPLIT3>
+template <int MT, int NT, int WM, int WN, int BK, bool GEMM1X1, int NP>
 __device__ __forceinline__ void conv_mfma_body(const ConvParams& p, float* __restrict__ smem) {
+    // NP: 0 = fp32 MFMA tiles; 3 = split-bf16 tiles (exact three-way split, six bf16 MFMAs per product, fp32 results);
+    // 1 = bf16 tiles (the net's "precision 1" mode: operands rounded once to bf16, ONE MFMA per product, fp32 accumulation)
+    constexpr bool SPLIT3 = NP != 0;
+    constexpr int WPL = NP == 1 ? 3 : 0;        // first weight plane read: [h, m, l, r] -- r = the bf16 rounding
     constexpr int BM = 16 * MT * WM, BN = 16 * NT * WN;
-    static_assert(!SPLIT3 || BK == 32, "split-bf16 tiles: one K = 32 MFMA step per tile");
+    static_assert(NP == 0 || BK == 32, "split-bf16 / bf16 tiles: one K = 32 MFMA step per tile");
     // LDS tile rows: BK >= 32 uses UNPADDED rows with an XOR swizzle of the 16-byte column index,
     // col ^ f(row) with f = (row >> 1) & 7 (BK 32) / row & 15 (BK 64).  Under gfx950's actual
     // ds_read_b128 / ds_write_b128 lane grouping ({0-3,12-15,20-27}, {4-11,16-19,28-31}, ...) this
@@ -43,7 +47,7 @@ __device__ __forceinline__ void conv_mfma_body(const ConvParams& p, float* __res
     static_assert(NTHR == 256 || (SPLIT3 && NTHR == 512), "4 waves per block (8: split-bf16 only)");
     // two LDS stages: tile kt+1 is written while tile kt is multiplied -> one barrier per K tile
     // (fp32: 2 * (BM + BN) * LDK floats; split-bf16: 2 stages x 3 planes x (BM + BN) rows of 32 bf16 = 64 bytes)
-    constexpr int STAGE_FLOATS = SPLIT3 ? (BM + BN) * 48 : (BM + BN) * LDK;
+    constexpr int STAGE_FLOATS = SPLIT3 ? (BM + BN) * 16 * NP : (BM + BN) * LDK;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
@@ -66,7 +70,7 @@ __device__ __forceinline__ void conv_mfma_body(const ConvParams& p, float* __res
     int woff[WP];              // bytes, relative to wbase
     // split-bf16: the weights come pre-split (three bf16 planes [3][Npad][Kpad] behind the packed fp32 weights,
     // launch_pack_split): 16-byte units (plane, row, quad of 8 k) straight into their swizzled LDS slots
-    constexpr int WU3 = BN * 12, WP3 = SPLIT3 ? (WU3 + NTHR - 1) / NTHR : 1;
+    constexpr int WU3 = BN * 4 * (SPLIT3 ? NP : 1), WP3 = SPLIT3 ? (WU3 + NTHR - 1) / NTHR : 1;
     int w3off[WP3], w3dst[WP3];
     const short* w3base = nullptr;
     if constexpr (SPLIT3) {
@@ -77,7 +81,7 @@ __device__ __forceinline__ void conv_mfma_body(const ConvParams& p, float* __res
             const int pl = u / (BN * 4), rem = u - pl * (BN * 4);
             const int row = rem >> 2, q = rem & 3;
             const int r = min(row, min(BN, p.Npad - n0) - 1);     // clamped: rows past the tile / Npad are never used
-            w3off[ps] = pl * p.Npad * p.Kpad + r * p.Kpad + q * 8;
+            w3off[ps] = (pl + WPL) * p.Npad * p.Kpad + r * p.Kpad + q * 8;
             w3dst[ps] = (pl * BN + row) * 64 + ((q ^ ((row >> 1) & 3)) << 4);
         }
     }
@@ -257,12 +261,17 @@ __device__ __forceinline__ void conv_mfma_body(const ConvParams& p, float* __res
         const int xcol = ((((kq >> 1) ^ (((tid / UPR) >> 1) & 3)) << 4)) + (kq & 1) * 8;
         auto store3 = [&](int stage, const f32x4 (&X)[XP], const bf16x8 (&W)[WP3], const unsigned vm) {
             char* Xs = reinterpret_cast<char*>(smem + stage * STAGE_FLOATS);
-            char* Ws = Xs + 3 * BM * 64;
+            char* Ws = Xs + NP * BM * 64;
 #pragma unroll
             for (int ps = 0; ps < XP; ++ps) {
                 const int u = tid + ps * NTHR;
                 if (XU % NTHR == 0 || u < XU) {
                     const f32x4 v = (GEMM1X1 || ((vm >> ps) & 1u)) ? X[ps] : f32x4{0.f, 0.f, 0.f, 0.f};
+                    char* d = Xs + (u / UPR) * 64 + xcol;
+                    if constexpr (NP == 1) {
+                        *reinterpret_cast<uint2*>(d) = rne4(v);
+                        continue;
+                    }
                     uint2 h, m, l;
                     if (SSD_C3_ABLATE & 4) {
                         h = make_uint2(__float_as_uint(v[0]), __float_as_uint(v[1]));
@@ -271,7 +280,6 @@ __device__ __forceinline__ void conv_mfma_body(const ConvParams& p, float* __res
                     } else
                     split4(v, h, m, l);
                     if (SSD_C3_ABLATE & 16) { asm volatile("" ::"v"(h), "v"(m), "v"(l)); continue; }
-                    char* d = Xs + (u / UPR) * 64 + xcol;
                     *reinterpret_cast<uint2*>(d) = h;
                     *reinterpret_cast<uint2*>(d + BM * 64) = m;
                     *reinterpret_cast<uint2*>(d + 2 * BM * 64) = l;
@@ -287,30 +295,30 @@ __device__ __forceinline__ void conv_mfma_body(const ConvParams& p, float* __res
         auto mma_tile = [&](int stage) {
             if (SSD_C3_ABLATE & 2) return;
             const char* Xb = reinterpret_cast<const char*>(smem + stage * STAGE_FLOATS);
-            const char* Wb = Xb + 3 * BM * 64;
-            B3 b[MT];
+            const char* Wb = Xb + NP * BM * 64;
+            BP<NP> b[MT];
 #pragma unroll
             for (int mi = 0; mi < MT; ++mi) {
                 const char* r = Xb + ((wm * MT + mi) * 16 + frow) * 64 + fq;
-                b[mi].h = *reinterpret_cast<const bf16x8*>(r);
-                b[mi].m = *reinterpret_cast<const bf16x8*>(r + BM * 64);
-                b[mi].l = *reinterpret_cast<const bf16x8*>(r + 2 * BM * 64);
+#pragma unroll
+                for (int pl = 0; pl < NP; ++pl) b[mi].p[pl] = *reinterpret_cast<const bf16x8*>(r + pl * BM * 64);
             }
 #pragma unroll
             for (int ni = 0; ni < NT; ++ni) {
                 const char* r = Wb + ((wn * NT + ni) * 16 + frow) * 64 + fq;
-                B3 a;
-                a.h = *reinterpret_cast<const bf16x8*>(r);
-                a.m = *reinterpret_cast<const bf16x8*>(r + BN * 64);
-                a.l = *reinterpret_cast<const bf16x8*>(r + 2 * BN * 64);
+                BP<NP> a;
+#pragma unroll
+                for (int pl = 0; pl < NP; ++pl) a.p[pl] = *reinterpret_cast<const bf16x8*>(r + pl * BN * 64);
                 if (SSD_C3_ABLATE & 1) {
 #pragma unroll
-                    for (int mi = 0; mi < MT; ++mi) asm volatile("" ::"v"(a.h), "v"(a.m), "v"(a.l), "v"(b[mi].h), "v"(b[mi].m), "v"(b[mi].l));
+                    for (int mi = 0; mi < MT; ++mi)
+#pragma unroll
+                        for (int pl = 0; pl < NP; ++pl) asm volatile("" ::"v"(a.p[pl]), "v"(b[mi].p[pl]));
                     continue;
                 }
                 // (issuing the six products term by term across the MT accumulators measured no faster than the chains)
 #pragma unroll
-                for (int mi = 0; mi < MT; ++mi) acc[mi][ni] = mma6(a, b[mi], acc[mi][ni]);
+                for (int mi = 0; mi < MT; ++mi) acc[mi][ni] = mmaN<NP>(a, b[mi], acc[mi][ni]);
             }
         };
         // 8 waves: the second wave group runs its half of the staging BEFORE its MFMAs ("ping-pong"): on every SIMD
@@ -492,14 +500,20 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvParams p) {
     constexpr bool SWZ = BK >= 32;
     constexpr int LDK = SWZ ? BK : BK + 4;
     __shared__ __attribute__((aligned(16))) float smem[2 * 16 * (MT * WM + NT * WN) * LDK];
-    conv_mfma_body<MT, NT, WM, WN, BK, GEMM1X1, false>(p, smem);
+    conv_mfma_body<MT, NT, WM, WN, BK, GEMM1X1, 0>(p, smem);
 }
 
 // split-bf16 variant: dynamic LDS, 2 * 3 * 16 * (MT*WM + NT*WN) * 64 bytes
 template <int MT, int NT, int WM, int WN, bool GEMM1X1>
 __global__ __launch_bounds__(64 * WM * WN) void conv_mfma3_kernel(const ConvParams p) {
     extern __shared__ __attribute__((aligned(16))) float smem3[];
-    conv_mfma_body<MT, NT, WM, WN, 32, GEMM1X1, true>(p, smem3);
+    conv_mfma_body<MT, NT, WM, WN, 32, GEMM1X1, 3>(p, smem3);
+}
+// bf16 variant (the net's precision-1 mode): one plane per operand, 2 * 16 * (MT*WM + NT*WN) * 64 bytes of LDS
+template <int MT, int NT, int WM, int WN, bool GEMM1X1>
+__global__ __launch_bounds__(64 * WM * WN) void conv_bf16_kernel(const ConvParams p) {
+    extern __shared__ __attribute__((aligned(16))) float smem1[];
+    conv_mfma_body<MT, NT, WM, WN, 32, GEMM1X1, 1>(p, smem1);
 }
 
 }  // namespace ssd

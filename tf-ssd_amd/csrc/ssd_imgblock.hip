@@ -30,6 +30,7 @@
 //   G = 1 (B >= #CUs): direct epilogue, no slabs.
 #include <cstdlib>
 
+#include "ssd_bf16x3.h"
 #include "ssd_conv.h"
 
 namespace ssd {
@@ -395,6 +396,231 @@ __global__ __launch_bounds__(kIThreads) void mbv2_image_block_kernel(const Fused
 #undef IDUMP
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// The same block on the BF16 matrix cores (the net's precision-1 "bf16" mode: NP = 1, every operand of the two 1x1
+// convolutions rounded once to bf16, ONE v_mfma_f32_16x16x32_bf16 per product, fp32 accumulation; NP = 3 -- the exact
+// three-way split, fp32 results -- compiles from the same source for experiments).  Differences to the kernel above:
+//   * X is converted once into bf16 B fragments (lane = pixel x 8 channels per 32-wide k-step): CIN / 8 registers per
+//     pixel tile instead of CIN / 4
+//   * no weight staging in LDS: the A fragments of the expand (bf16 plane of the scale-folded We, [Ce][kpad_e]) and of the
+//     project ([npad_p][kpad_p]) are read straight from L1 / L2, one chunk ahead of their use
+//   * the project runs every SECOND 16-channel chunk on K = 32 = the two chunks' depthwise outputs (k-slot (g4, j):
+//     j < 4 -> even chunk channel g4*4 + j, j >= 4 -> odd chunk), converted in registers
+//   * E, the depthwise taps, the BatchNorm shifts, ReLU6, the residual add and the partial-sum slabs stay fp32
+typedef short bf16x4 __attribute__((ext_vector_type(4)));
+
+template <int CIN, int NT, int T, int S, int NP>
+__global__ __launch_bounds__(kIThreads) void mbv2_image16_block_kernel(const FusedBlockParams p) {
+    static_assert(CIN % 32 == 0, "whole 32-channel k-steps");
+    constexpr int WPL = NP == 1 ? 3 : 0;          // first plane read of [h, m, l, r]
+    constexpr int KS = CIN / 32;                  // k-steps of the expand
+    constexpr int TO = S == 1 ? T : 1;            // output pixel tiles per wave
+    constexpr int NCH = T == 1 ? 2 : 1;           // independent expand accumulator chains per tile
+
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, g4 = lane >> 4;
+    const int G = p.groups, B = p.B;
+    const int grp = blockIdx.x / B, img = blockIdx.x - grp * B;
+    const int H = p.H, W = p.W, P = W + 1, Q = H * P;
+    const int npt = (Q + 15) >> 4;
+    const int NE = npt * 16 + 2 * P + 2;          // E rows: index q + P + 1, zero rows above / below
+    const int CeG = p.Ce / G, cbeg = grp * CeG, nchunk = CeG / kIC;
+
+    float* Es = sm;                               // [2][NE][kILD]
+    float* Ps = Es + 2 * NE * kILD;               // [11][CeG]: expand shift, depthwise taps [9], depthwise shift
+    const long plane_e = (long)p.Ce * p.kpad_e, plane_p = (long)p.npad_p * p.kpad_p;
+    const short* we16 = p.we3 + WPL * plane_e;
+    const short* wp16 = p.wp3 + WPL * plane_p;
+
+    for (int u = tid; u < 2 * (2 * P + 2) * (kILD / 4); u += kIThreads) {
+        const int buf = u / ((2 * P + 2) * (kILD / 4)), v = u - buf * ((2 * P + 2) * (kILD / 4));
+        const int row = v / (kILD / 4), c4 = (v - row * (kILD / 4)) * 4;
+        const int e = row < P + 1 ? row : npt * 16 + row;          // rows [0, P] and [npt*16 + P + 1, NE)
+        *reinterpret_cast<f32x4*>(Es + (buf * NE + e) * kILD + c4) = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    BP<NP> xs[T][KS];
+    int qs[T];
+    bool tvalid[T], real[T];
+    int opix[T];
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+        const int tile = wave * T + t;
+        tvalid[t] = tile < npt;
+        const int q = tile * 16 + l15;
+        const int r = q / P, c = q - r * P;
+        real[t] = tvalid[t] && q < Q && c < W;
+        qs[t] = tvalid[t] ? q : 0;
+        opix[t] = real[t] ? r * W + c : 0;
+        const float* xp = p.x + ((long)img * H * W + opix[t]) * CIN + g4 * 8;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const f32x4 lo = real[t] ? *reinterpret_cast<const f32x4*>(xp + ks * 32) : f32x4{0.f, 0.f, 0.f, 0.f};
+            const f32x4 hi = real[t] ? *reinterpret_cast<const f32x4*>(xp + ks * 32 + 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+            xs[t][ks] = splitN<NP>(lo, hi);
+        }
+    }
+    const int Ho = p.Ho, Wo = p.Wo;
+    int qo[TO], opo[TO];
+    bool realo[TO];
+#pragma unroll
+    for (int t = 0; t < TO; ++t) {
+        if (S == 1) {
+            qo[t] = qs[t];
+            opo[t] = opix[t];
+            realo[t] = real[t];
+        } else {
+            const int Po = Wo + 1, tile = wave * TO + t;
+            const int q = tile * 16 + l15;
+            const int ro = q / Po, co = q - ro * Po;
+            realo[t] = tile * 16 < Ho * Po && q < Ho * Po && co < Wo;
+            qo[t] = (tile * 16 < Ho * Po && q < Ho * Po) ? (2 * ro - p.pad_t + 1) * P + (2 * co - p.pad_l + 1) : 0;
+            opo[t] = realo[t] ? ro * Wo + co : 0;
+        }
+    }
+    for (int u = tid; u < 11 * (CeG / 4); u += kIThreads) {
+        const int row = u / (CeG / 4), c4 = (u - row * (CeG / 4)) * 4;
+        const float* src = row == 0 ? p.eh : row == 10 ? p.dh : p.wd + (long)(row - 1) * p.Ce;
+        *reinterpret_cast<f32x4*>(Ps + row * CeG + c4) = *reinterpret_cast<const f32x4*>(src + cbeg + c4);
+    }
+    // expand A fragments of chunk j: row = the chunk's channel l15, k = ks*32 + g4*8 .. +7
+    auto load_we = [&](BP<NP> (&w)[KS], int j) {
+        const short* wr = we16 + (long)(cbeg + j * kIC + l15) * p.kpad_e + g4 * 8;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+            for (int pl = 0; pl < NP; ++pl) w[ks].p[pl] = *reinterpret_cast<const bf16x8*>(wr + pl * plane_e + ks * 32);
+    };
+    BP<NP> wea[KS];
+    load_we(wea, 0);
+    __syncthreads();
+
+    auto expand = [&](int j) {
+        f32x4 ea[T][NCH];
+        const f32x4 sh = *reinterpret_cast<const f32x4*>(Ps + j * kIC + g4 * 4);
+#pragma unroll
+        for (int t = 0; t < T; ++t) {
+            ea[t][0] = sh;
+            if (NCH == 2) ea[t][NCH - 1] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+            for (int t = 0; t < T; ++t) ea[t][ks % NCH] = mmaN<NP>(wea[ks], xs[t][ks], ea[t][ks % NCH]);
+        float* es = Es + ((j & 1) * NE + P + 1) * kILD + g4 * 4;
+#pragma unroll
+        for (int t = 0; t < T; ++t) {
+            f32x4 v = ea[t][0];
+            if (NCH == 2) v = v + ea[t][NCH - 1];
+            const float hi = real[t] ? 6.0f : 0.0f;       // relu6 at real pixels, 0 at pad positions
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = __builtin_amdgcn_fmed3f(v[e], 0.0f, hi);
+            if (tvalid[t]) *reinterpret_cast<f32x4*>(es + qs[t] * kILD) = v;
+            if (p.e_out && real[t])
+                *reinterpret_cast<f32x4*>(p.e_out + ((long)img * H * W + opix[t]) * p.Ce + cbeg + j * kIC + g4 * 4) = v;
+        }
+    };
+
+    f32x4 acc[TO][NT];
+#pragma unroll
+    for (int t = 0; t < TO; ++t)
+#pragma unroll
+        for (int ni = 0; ni < NT; ++ni) acc[t][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    expand(0);
+    if (nchunk > 1) load_we(wea, 1);
+    f32x4 dprev[TO];
+
+    for (int i = 0; i < nchunk; ++i) {
+        lds_barrier();          // E(i) is visible; everyone is done with E(i - 1)
+        const bool odd = i & 1;
+        const bool flush = odd || i + 1 == nchunk;
+        // project A fragments of the chunk pair (i - 1, i) / the lone last chunk: in flight across the depthwise
+        bf16x4 wlo[NT][NP], whi[NT][NP];
+        if (flush) {
+            const short* wr = wp16 + (long)l15 * p.kpad_p + cbeg + (i & ~1) * kIC + g4 * 4;
+#pragma unroll
+            for (int ni = 0; ni < NT; ++ni)
+#pragma unroll
+                for (int pl = 0; pl < NP; ++pl) {
+                    const short* r = wr + (long)ni * 16 * p.kpad_p + pl * plane_p;
+                    wlo[ni][pl] = *reinterpret_cast<const bf16x4*>(r);
+                    whi[ni][pl] = odd ? *reinterpret_cast<const bf16x4*>(r + kIC) : bf16x4{0, 0, 0, 0};
+                }
+        }
+        // ---- depthwise in MFMA-fragment layout
+        f32x4 a[TO];
+        {
+            const f32x4 dh = *reinterpret_cast<const f32x4*>(Ps + 10 * CeG + i * kIC + g4 * 4);
+#pragma unroll
+            for (int t = 0; t < TO; ++t) a[t] = dh;
+            const float* es = Es + ((i & 1) * NE + P + 1) * kILD + g4 * 4;
+#pragma unroll
+            for (int dy = -1; dy <= 1; ++dy)
+#pragma unroll
+                for (int dx = -1; dx <= 1; ++dx) {
+                    const f32x4 w = *reinterpret_cast<const f32x4*>(Ps + (1 + (dy + 1) * 3 + dx + 1) * CeG + i * kIC + g4 * 4);
+#pragma unroll
+                    for (int t = 0; t < TO; ++t) {
+                        const f32x4 e = *reinterpret_cast<const f32x4*>(es + (qo[t] + (S == 1 ? dy * P + dx : dy * P + dx)) * kILD);
+                        a[t] += e * w;
+                    }
+                }
+#pragma unroll
+            for (int t = 0; t < TO; ++t)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) a[t][e] = __builtin_amdgcn_fmed3f(a[t][e], 0.0f, 6.0f);
+        }
+        // ---- project (every second chunk: K = 32)
+        if (!flush) {
+#pragma unroll
+            for (int t = 0; t < TO; ++t) dprev[t] = a[t];
+        } else {
+            BP<NP> d[TO];
+#pragma unroll
+            for (int t = 0; t < TO; ++t) d[t] = odd ? splitN<NP>(dprev[t], a[t]) : splitN<NP>(a[t], f32x4{0.f, 0.f, 0.f, 0.f});
+#pragma unroll
+            for (int ni = 0; ni < NT; ++ni) {
+                BP<NP> wa;
+#pragma unroll
+                for (int pl = 0; pl < NP; ++pl) wa.p[pl] = __builtin_shufflevector(wlo[ni][pl], whi[ni][pl], 0, 1, 2, 3, 4, 5, 6, 7);
+#pragma unroll
+                for (int t = 0; t < TO; ++t) acc[t][ni] = mmaN<NP>(wa, d[t], acc[t][ni]);
+            }
+        }
+        if (i + 1 < nchunk) {
+            expand(i + 1);
+            if (i + 2 < nchunk) load_we(wea, i + 2);        // in flight across the barrier and the next depthwise
+        }
+    }
+
+    // ---- epilogue (fp32): G = 1 direct; G > 1 partial-sum slab, combined by image_combine_kernel
+    const long img_off = (long)img * Ho * Wo * p.Cout;
+    if (G == 1) {
+#pragma unroll
+        for (int t = 0; t < TO; ++t) {
+            if (!realo[t]) continue;
+            float* yp = p.y + img_off + (long)opo[t] * p.Cout + g4 * 4;
+#pragma unroll
+            for (int ni = 0; ni < NT; ++ni) {
+                f32x4 v = acc[t][ni] + *reinterpret_cast<const f32x4*>(p.ph + ni * 16 + g4 * 4);
+                if (p.residual)
+                    v = v + *reinterpret_cast<const f32x4*>(p.x + img_off + (long)opo[t] * p.Cout + ni * 16 + g4 * 4);
+                *reinterpret_cast<f32x4*>(yp + ni * 16) = v;
+            }
+        }
+        return;
+    }
+    const long slab_stride = (long)B * Ho * Wo * p.Cout;
+    float* sp = p.slabs + (long)grp * slab_stride + img_off + g4 * 4;
+#pragma unroll
+    for (int t = 0; t < TO; ++t) {
+        if (!realo[t]) continue;
+#pragma unroll
+        for (int ni = 0; ni < NT; ++ni) *reinterpret_cast<f32x4*>(sp + (long)opo[t] * p.Cout + ni * 16) = acc[t][ni];
+    }
+}
+
 // y = shift + sum of the G slabs in group order (+ residual): the combine as its own launch
 __global__ __launch_bounds__(256) void image_combine_kernel(const float* __restrict__ slabs, const float* __restrict__ ph,
                                                             const float* __restrict__ xres, float* __restrict__ y,
@@ -419,9 +645,10 @@ typedef void (*image_kernel_t)(const FusedBlockParams);
 struct ImageCfg {
     int cin, nt, t, stride;
     image_kernel_t fn;
+    image_kernel_t fn16;        // the bf16 form (precision 1)
 };
-#define ICFG(CIN, NT, T) {CIN, NT, T, 1, mbv2_image_block_kernel<CIN, NT, T, 1>}
-#define ICFG2(CIN, NT, T) {CIN, NT, T, 2, mbv2_image_block_kernel<CIN, NT, T, 2>}
+#define ICFG(CIN, NT, T) {CIN, NT, T, 1, mbv2_image_block_kernel<CIN, NT, T, 1>, mbv2_image16_block_kernel<CIN, NT, T, 1, 1>}
+#define ICFG2(CIN, NT, T) {CIN, NT, T, 2, mbv2_image_block_kernel<CIN, NT, T, 2>, mbv2_image16_block_kernel<CIN, NT, T, 2, 1>}
 const ImageCfg kImage[] = {
     ICFG(64, 4, 3),     // blocks 7-9:   64 -> 384 -> 64 at 19x19
     ICFG(64, 6, 3),     // block 10:     64 -> 384 -> 96
@@ -433,6 +660,7 @@ const ImageCfg kImage[] = {
 
 size_t image_lds_bytes(const ImageCfg& c, const FusedBlockParams& p, int G) {
     const int P = p.W + 1, npt = (p.H * P + 15) / 16, NE = npt * 16 + 2 * P + 2;
+    if (p.bf16) return ((size_t)2 * NE * kILD + (size_t)11 * (p.Ce / G) + 4) * sizeof(float);      // no weight tiles in LDS
     const size_t fl = (size_t)2 * NE * kILD + (size_t)2 * kIC * (c.cin + 8) + (size_t)2 * c.nt * 16 * kILD +
                       (size_t)11 * (p.Ce / G) + 4;
     return fl * sizeof(float);
@@ -498,12 +726,15 @@ int launch_image_block(FusedBlockParams p, hipStream_t st) {
     SSD_CHECK_ARG(p.groups == 1 || p.slabs, "image block: %d groups need the slab workspace", p.groups);
     const size_t lds = image_lds_bytes(*c, p, p.groups);
     SSD_UNSUPPORTED_IF(lds > 160 * 1024, "image block: needs %zu B of LDS", lds);
+    SSD_CHECK_ARG(!p.bf16 || (p.we3 && p.wp3), "image block: the bf16 form needs the weights' bf16 planes");
+    SSD_CHECK_ARG(!p.bf16 || !p.tickets, "image block: the bf16 form combines by the second launch only");
+    const image_kernel_t fn = p.bf16 ? c->fn16 : c->fn;
     if (lds > 64 * 1024)
-        SSD_HIP(hipFuncSetAttribute((const void*)c->fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        SSD_HIP(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     // groups > 1: p.tickets == nullptr (default) combines the group slabs in a second launch -- the
     // launch boundary publishes them and every CU takes part (B=64: 43 us per block 7 instead of 46);
     // with tickets the last arriving group of each image combines inside the launch.
-    hipLaunchKernelGGL(c->fn, dim3((unsigned)((long)p.B * p.groups)), dim3(kIThreads), lds, st, p);
+    hipLaunchKernelGGL(fn, dim3((unsigned)((long)p.B * p.groups)), dim3(kIThreads), lds, st, p);
     SSD_LAUNCH_CHECK();
     if (p.groups > 1 && !p.tickets && !(p.ablate & 24)) {
         const long nvec = (long)p.B * p.Ho * p.Wo * p.Cout / 4;

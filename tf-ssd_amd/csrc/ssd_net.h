@@ -86,6 +86,7 @@ struct ssd_net {
     bool fuse_blocks = true;        // run eligible inverted-residual blocks as one fused kernel
     bool fuse_dwproj = true;        // ... and depthwise + project of the others as one kernel
     bool use_wino = true;           // offer the Winograd F(2x2,3x3) kernels to the autotune
+    int precision = 0;              // 0: fp32 results everywhere (the reference's arithmetic); 1: "bf16" -- every matrix operand of the dense / 1x1 convs rounded once to bf16, one bf16 MFMA per product, fp32 accumulation and epilogues (BASELINE.json configs[3] / [4])
     int fuse_band = 2;              // blocks 1-6: 2 row-band kernel with the 1x1 convs on the bf16 matrix cores through an exact 3-way split (ssd_band3.hip), 1 row-band kernel on the fp32 MFMA (ssd_bandblock.hip), 0 the 8x8-tile kernel
     int fuse_image = 1;             // whole-image block kernel (ssd_imgblock.hip): 0 never, 1 where it won the finalize-time race, 2 wherever it applies
     int lanes_hint = 1;             // replicas of this net running concurrently (lanes): the whole-image kernel then splits an image's expanded channels over fewer workgroups (B x groups x lanes fills the CUs; fewer slab passes)

@@ -306,6 +306,7 @@ static ConvParams layer_conv_params(const ssd_net& net, const Layer& l, int B, c
     p.in = in;
     p.w = l.packed;
     p.w3 = conv_split_planes(l.packed, l.kh * l.kw * l.Cin, l.Cout);
+    p.bf16 = net.precision;
     p.wino_w = l.wino;
     p.scale = l.scale;
     p.shift = l.shift;
@@ -355,9 +356,12 @@ static FusedBlockParams fused_params(const ssd_net& net, const Layer& f, int B) 
     p.kpad_p = conv_kpad(lp.Cin);
     p.npad_p = conv_npad(lp.Cout);
     p.e_out = f.e_out >= 0 ? net.tensors[f.e_out].dev : nullptr;
-    p.we3 = reinterpret_cast<const short*>(f.fz_we3);
+    p.we3 = reinterpret_cast<const short*>(f.fz_we3);        // band kernel's plane layout (blocks 1-6) ...
     p.wp3 = reinterpret_cast<const short*>(f.fz_wp3);
+    p.bf16 = net.precision;
     if (!fused_block_supported(p) && image_block_supported(p)) {
+        p.we3 = conv_split_planes(f.fz_we, le.Cin, le.Cout);  // ... whole-image kernel: plain [4][Ce][kpad_e] / [4][npad_p][kpad_p] planes
+        p.wp3 = conv_split_planes(f.fz_wp, lp.Cin, lp.Cout);
         p.groups = net.img_slabs ? image_block_groups(p, B * net.lanes_hint) : 1;
         p.slabs = net.img_slabs;
         p.tickets = net.image_ticket ? net.img_tickets : nullptr;
@@ -571,7 +575,7 @@ static int autotune(ssd_net& net, int B, hipStream_t st) {
                 const int split = kSplits[si];
                 l.split_k = split;
                 ConvParams p = layer_conv_params(net, l, B, in, out, res, d, pr);
-                if (!conv_config_valid(c, p)) break;
+                if (!conv_config_valid(c, p) || !conv_config_allowed(c, net.precision)) break;
                 const bool direct = (c == conv_num_configs() - 1);
                 if (direct && (best_cfg >= 0 || split > 1)) break;     // direct only as a last resort
                 if (split > 1) {
@@ -893,16 +897,19 @@ int ssd_net_finalize(ssd_net* net, int max_batch) {
         const Layer& le = net->layers[f.f_expand];
         const Layer& ld = net->layers[f.f_dw];
         const Layer& lp = net->layers[f.f_project];
-        const size_t ne = (size_t)conv_kpad(le.Cin) * conv_npad(le.Cout), nd = (size_t)9 * ld.Cout,
-                     np = (size_t)conv_kpad(lp.Cin) * conv_npad(lp.Cout);
-        int rc = dev_alloc(*net, ne, &f.fz_we);
+        const size_t nd = (size_t)9 * ld.Cout;
+        // (the two 1x1 matrices with room for their four bf16 planes behind them, like every packed conv weight)
+        int rc = dev_alloc(*net, conv_packed_floats(le.Cin, le.Cout), &f.fz_we);
         if (!rc) rc = dev_alloc(*net, nd, &f.fz_wd);
-        if (!rc) rc = dev_alloc(*net, np, &f.fz_wp);
+        if (!rc) rc = dev_alloc(*net, conv_packed_floats(lp.Cin, lp.Cout), &f.fz_wp);
         if (rc) return rc;
         // packed [n][kpad]: row n scaled by scale[n]; depthwise [9][C]: column c scaled by scale[c]
         rc = launch_scale_rows(le.packed, le.scale, conv_npad(le.Cout), le.Cout, conv_kpad(le.Cin), f.fz_we, st);
         if (!rc) rc = launch_scale_cols(net->params[ld.p_kernel].dev, ld.scale, 9, ld.Cout, f.fz_wd, st);
         if (!rc) rc = launch_scale_rows(lp.packed, lp.scale, conv_npad(lp.Cout), lp.Cout, conv_kpad(lp.Cin), f.fz_wp, st);
+        // bf16 planes (h, m, l exact split + r rounding) of both: the bf16 form of the whole-image kernel reads plane r
+        if (!rc) rc = launch_pack_split(f.fz_we, le.Cin, le.Cout, st);
+        if (!rc) rc = launch_pack_split(f.fz_wp, lp.Cin, lp.Cout, st);
         if (rc) return rc;
         // split-bf16 band kernel: the same two matrices as three bf16 planes each (exact split, see ssd_band3.hip)
         f.fz_we3 = f.fz_wp3 = nullptr;
@@ -968,7 +975,7 @@ int ssd_net_finalize(ssd_net* net, int max_batch) {
         int cfg = -1;
         for (int c = 0; c < conv_num_configs(); ++c)
             if (it->second.first == conv_config_name(c)) cfg = c;
-        if (cfg < 0) { ++n_tuned; continue; }
+        if (cfg < 0 || !conv_config_allowed(cfg, net->precision)) { ++n_tuned; continue; }
         l.cfg = cfg;
         l.split_k = it->second.second;
         ConvParams p = layer_conv_params(*net, l, max_batch, net->tensors[l.in].dev,
@@ -1394,6 +1401,13 @@ int ssd_net_set_option(ssd_net* net, const char* name, int value) {
         net->drop_graphs();
         return SSD_OK;
     }
+    if (std::string(name) == "precision") {      // 0 fp32 (default), 1 bf16 matrix operands (see ssd_net.h); takes effect at the next finalize
+        SSD_CHECK_ARG(value == 0 || value == 1, "ssd_net_set_option: precision must be 0 (fp32) or 1 (bf16)");
+        if (net->precision != value) net->finalized = false;
+        net->precision = value;
+        net->drop_graphs();
+        return SSD_OK;
+    }
     if (std::string(name) == "fuse_band") {      // blocks 1-6: 2 (default) split-bf16 row-band kernel, 1 fp32-MFMA row-band kernel, 0 the 8x8-tile kernel
         net->fuse_band = value < 0 ? 0 : (value > 2 ? 2 : value);
         net->drop_graphs();
@@ -1511,9 +1525,19 @@ const char* ssd_net_layer_kind(const ssd_net* net, int i) {
     return (net && i >= 0 && i < (int)net->layers.size()) ? kKindName[net->layers[i].kind] : "";
 }
 const char* ssd_net_layer_config(const ssd_net* net, int i) {
-    if (!net || i < 0 || i >= (int)net->layers.size() || net->layers[i].kind != LK_CONV) return "";
+    if (!net || i < 0 || i >= (int)net->layers.size()) return "";
     static thread_local char buf[64];
     const Layer& l = net->layers[i];
+    if (l.kind == LK_FUSED) {        // which fused kernel family runs the block (bench.py prices each at its matrix instruction)
+        if (!layer_runs(*net, l)) return "";
+        if (l.f_type == 1) return "stem";
+        if (l.f_type == 2) return "dwproj";
+        const FusedBlockParams p = fused_params(*net, l, 1);
+        if (!fused_block_supported(p)) return net->precision ? "image_bf16" : "image";
+        if (net->fuse_band == 2 && p.we3 && band3_block_supported(p)) return net->precision ? "band_bf16" : "band3";
+        return net->fuse_band && band_block_supported(p) ? "band" : "tile";
+    }
+    if (l.kind != LK_CONV) return "";
     if (l.split_k > 1) snprintf(buf, sizeof(buf), "%s/s%d", conv_config_name(l.cfg), l.split_k);
     else snprintf(buf, sizeof(buf), "%s", conv_config_name(l.cfg));
     return buf;

@@ -17,6 +17,7 @@
 #include <cmath>
 #include <cstring>
 
+#include "ssd_bf16x3.h"
 #include "ssd_net.h"
 
 using namespace ssd;
@@ -153,14 +154,15 @@ __global__ __launch_bounds__(256) void pack_jobs_kernel(const PackJob* __restric
             }
         }
         j.dst[e] = v;
-        // the same matrix split into its three bf16 planes behind the fp32 one (split-bf16 conv tiles, ssd_conv3.hip)
+        // the same matrix as four bf16 planes behind the fp32 one: the exact split h, m, l (split-bf16 conv tiles,
+        // ssd_conv3.hip) and the bf16 rounding r (bf16 tiles)
         short* pl = reinterpret_cast<short*>(j.dst + total);
-        const unsigned hb = __float_as_uint(v) & 0xffff0000u;
-        const float r1 = v - __uint_as_float(hb);
-        const unsigned mb = __float_as_uint(r1) & 0xffff0000u;
-        pl[e] = (short)(hb >> 16);
-        pl[total + e] = (short)(mb >> 16);
-        pl[2 * total + e] = (short)(__float_as_uint(r1 - __uint_as_float(mb)) >> 16);
+        short h, m, l;
+        split1(v, h, m, l);
+        pl[e] = h;
+        pl[total + e] = m;
+        pl[2 * total + e] = l;
+        pl[3 * total + e] = rne1(v);
     }
 }
 
@@ -858,6 +860,7 @@ struct TrainLayer {
 struct ssd_train_state {
     int batch = 0;
     size_t P = 0;
+    double step_flops[3] = {0, 0, 0};   // matrix-core FLOPs of the last forward_backward: fp32-MFMA convs, split-bf16 convs, weight gradients
     float *flat = nullptr, *m = nullptr, *v = nullptr;
     std::vector<long> poff;             // parameter -> offset in the flat trainable vector (-1: not trainable)
     std::vector<float*> act;            // training activations per tensor (own arena: no finalize needed)
@@ -1019,10 +1022,16 @@ static ConvParams dense_conv_params(int B, int H, int W, int Cin, int Cout, int 
     return p;
 }
 
+// matrix-core FLOPs issued by the step being built, per instruction family (bench.py prices each at its own peak):
+// [0] conv forward / backward-data on fp32-MFMA tiles, [1] on split-bf16 tiles, [2] weight gradients (fp32 MFMA)
+static thread_local double g_step_flops[3] = {0, 0, 0};
+
 static int launch_conv(ConvParams& p, hipStream_t st) {
     p.vec_store = (((uintptr_t)p.out & 15) == 0) && (p.out_pixel_stride % 4 == 0) && (p.out_batch_stride % 4 == 0);
     const int cfg = conv_pick_config(p);
     SSD_UNSUPPORTED_IF(cfg < 0, "train: no conv kernel for Cin=%d Cout=%d k=%dx%d", p.Cin, p.Cout, p.kh, p.kw);
+    const char* cn = conv_config_name(cfg);
+    g_step_flops[(strncmp(cn, "mfma3_", 6) == 0 || strncmp(cn, "bf16_", 5) == 0) ? 1 : 0] += 2.0 * (double)p.M * p.K * p.Cout;
     return conv_launch(p, cfg, st);
 }
 
@@ -1071,6 +1080,7 @@ static int wgrad(ssd_train_state& s, const Layer& l, int B, const float* x, cons
     p.partial = s.partial;
     hipLaunchKernelGGL(cfg->fn, dim3((unsigned)tiles, (unsigned)chunks), dim3(256), 0, st, p);
     SSD_LAUNCH_CHECK();
+    g_step_flops[2] += 2.0 * (double)p.M * p.K * N;
     return chunk_sum(s.partial, chunks, (long)kn, dW, st);
 }
 
@@ -1281,6 +1291,11 @@ int ssd_net_train_forward_backward(ssd_net* net, const float* image_dev, int B, 
     const int N = net->num_priors, L = net->L;
     s.act[0] = const_cast<float*>(image_dev);
     int rc = SSD_OK;
+    g_step_flops[0] = g_step_flops[1] = g_step_flops[2] = 0;
+    struct FlopsOut {           // whatever path returns: the state holds what this call issued
+        ssd_train_state& s;
+        ~FlopsOut() { for (int i = 0; i < 3; ++i) s.step_flops[i] = g_step_flops[i]; }
+    } flops_out{s};
 
     // re-pack the (just updated) weights of every conv: forward and backward-data forms, one launch
     if (s.n_pack_jobs) {
@@ -1310,6 +1325,7 @@ int ssd_net_train_forward_backward(ssd_net* net, const float* image_dev, int B, 
             p.in = x;
             p.w = t.wfwd;
             p.w3 = conv_split_planes(t.wfwd, l.kh * l.kw * l.Cin, l.Cout);
+            p.bf16 = net->precision;          // precision 1: the cost model takes the bf16 (one-product) tiles
             if (l.p_bn >= 0) {
                 p.out = t.pre;
                 p.act = SSD_ACT_NONE;
@@ -1539,6 +1555,7 @@ int ssd_net_train_forward_backward(ssd_net* net, const float* image_dev, int B, 
         p.in = gin;
         p.w = t.wbwd;
         p.w3 = conv_split_planes(t.wbwd, p.K, p.Cout);
+        p.bf16 = net->precision;
         p.out = s.gact[l.in];
         p.act = SSD_ACT_NONE;
         p.residual = s.gwritten[l.in] ? s.gact[l.in] : nullptr;      // accumulate in the epilogue
@@ -1634,6 +1651,13 @@ int ssd_net_adam_step(ssd_net* net, const float* grads_flat_dev, float lr, float
 }
 
 long ssd_net_train_steps(const ssd_net* net) { return (net && net->train) ? net->train->step : 0; }
+
+int ssd_net_train_matrix_flops(const ssd_net* net, double* out3) {
+    SSD_CHECK_ARG(net && out3, "ssd_net_train_matrix_flops: NULL argument");
+    if (!net->train) { set_error("ssd_net_train_matrix_flops: call ssd_net_train_begin() first"); return SSD_E_STATE; }
+    for (int i = 0; i < 3; ++i) out3[i] = net->train->step_flops[i];
+    return SSD_OK;
+}
 
 // Debug / parity hook: copy a buffer of the LAST ssd_net_train_forward_backward (at batch B) to the
 // host.  what = "probs" | "deltas" | "grad_logits" | "grad_deltas" | "<tensor name>" (training

@@ -20,7 +20,14 @@ class SSDModel(object):
     (pred_deltas [B,N,4], pred_labels [B,N,L])``; also ``predict``, ``load_weights``,
     ``save_weights``, ``get_weights``, ``set_weights``."""
 
-    def __init__(self, backbone, hyper_params, max_batch=None):
+    def __init__(self, backbone, hyper_params, max_batch=None, precision="fp32"):
+        """``precision``: "fp32" (default: the reference's arithmetic, fp32 results everywhere) or "bf16" (this
+        build's extension for BASELINE.json configs[3] / [4]: every matrix operand of the dense / 1x1 convolutions is
+        rounded once to bf16, one bf16 MFMA per product, fp32 accumulation; BatchNorm shifts, activations, residual
+        adds, depthwise taps, softmax and the box math stay fp32)."""
+        if precision not in ("fp32", "bf16"):
+            raise ValueError("precision must be 'fp32' or 'bf16', got %r" % (precision,))
+        self.precision = precision
         self.backbone = backbone
         self.hyper_params = hyper_params
         self.img_size = int(hyper_params["img_size"])
@@ -48,6 +55,8 @@ class SSDModel(object):
         self._weights_set = False
         self._weights_version = 0          # bumped by every weight change (lane replicas follow it)
         self._options = {}
+        if precision == "bf16":
+            self.set_option("precision", 1)
 
     def __del__(self):
         try:
@@ -81,7 +90,7 @@ class SSDModel(object):
     def clone(self):
         """An independent replica (own native net: arena, scratch, streams) with the same weights, options
         and tile tuning -- a second LANE for ``DecoderModel`` to keep two batches in flight."""
-        m = SSDModel(self.backbone, self.hyper_params, self._max_batch)
+        m = SSDModel(self.backbone, self.hyper_params, self._max_batch, precision=self.precision)
         m.set_weights(self.get_weights())
         for k, v in self._options.items():
             m.set_option(k, v)
@@ -180,6 +189,8 @@ class SSDModel(object):
         import tuning
         lib = _h.lib()
         key = tuning.table_key(self.backbone, self.img_size, self.total_labels, self.hyper_params["aspect_ratios"], want)
+        if self.precision != "fp32":
+            key += "_" + self.precision           # the bf16 mode has its own kernel families and its own tables
         opts = tuning.options_key({k: v for k, v in self._options.items() if k in _TABLE_OPTIONS})
         source, text, path = "autotune", None, None
         explicit = getattr(self, "_tuning_explicit", None)

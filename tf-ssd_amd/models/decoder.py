@@ -162,7 +162,7 @@ class DecoderModel(object):
                 best, best_t = (a, b), t
         self._lane_streams[0], self._lane_streams[1] = cands[best[0]], cands[best[1]]
         torch.cuda.synchronize()
-        for k, c in enumerate(cands):                  # the losing candidates are native streams of ours: destroy them
+        for k, c in enumerate(cands):                  # the losing candidates go back to the stream pool
             if k not in best:
                 _h.free_stream(c)
         # steady state of the chosen pair against one lane alone (the short trials flatter the pairing: with
@@ -244,12 +244,11 @@ class DecoderModel(object):
         return b, l, s
 
     def close(self):
-        """Release the lanes: their replicas of the net (arena, scratch) and their native streams."""
-        if self._lane_streams:
-            try:
-                torch.cuda.synchronize()
-            except Exception:
-                pass
+        """Release the lanes: their replicas of the net (arena, scratch); their streams go back to the process-wide
+        pool (ssd_hip.new_stream: never destroyed, reused by the next DecoderModel)."""
+        import sys
+        if sys.is_finalizing():
+            return
         for st in self._lane_streams:
             _h.free_stream(st)
         self._lane_streams = []

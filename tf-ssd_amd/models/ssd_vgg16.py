@@ -35,9 +35,9 @@ class L2Normalization(object):
     __call__ = call
 
 
-def get_model(hyper_params, max_batch=None):
+def get_model(hyper_params, max_batch=None, precision="fp32"):
     """reference models/ssd_vgg16.py:33-97."""
-    model = SSDModel("vgg16", hyper_params, max_batch=max_batch)
+    model = SSDModel("vgg16", hyper_params, max_batch=max_batch, precision=precision)
     model.set_weights(keras_default_init(model.param_specs, "vgg16"))
     return model
 

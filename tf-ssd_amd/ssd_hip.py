@@ -113,6 +113,7 @@ _SIGNATURES = {
     "ssd_net_adam_step": (ctypes.c_int, [vp, vp, ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_float,
                                          ctypes.c_float, vp]),
     "ssd_net_train_steps": (ctypes.c_long, [vp]),
+    "ssd_net_train_matrix_flops": (ctypes.c_int, [vp, ctypes.POINTER(ctypes.c_double)]),
     "ssd_net_train_fetch": (ctypes.c_long, [vp, ctypes.c_char_p, ctypes.c_int, c_float_p, ctypes.c_size_t]),
 }
 
@@ -167,28 +168,34 @@ def stream():
     return vp(torch.cuda.current_stream().cuda_stream)
 
 
+_stream_pool = {False: [], True: []}
+
+
 def new_stream(high_priority=False):
     """A non-blocking native stream (``ssd_stream_create``) as a torch stream object: not ordered against
-    the legacy NULL stream, unlike ``torch.cuda.Stream()`` on this stack (DecoderModel lanes)."""
+    the legacy NULL stream, unlike ``torch.cuda.Stream()`` on this stack (DecoderModel lanes).  Streams come from a
+    process-wide pool and go back to it with ``free_stream``: they are never destroyed while the process lives --
+    torch's caching allocator keeps references to every stream a tensor was ``record_stream``-ed on and touches them
+    when it recycles the block, so destroying a lane's stream crashes a later allocation (or the interpreter's exit).
+    Reuse bounds the number of native streams by the largest number ever in use at once."""
     device()
-    h = lib().ssd_stream_create(1 if high_priority else 0)
+    hp = bool(high_priority)
+    if _stream_pool[hp]:
+        return _stream_pool[hp].pop()
+    h = lib().ssd_stream_create(1 if hp else 0)
     if not h:
         raise SsdHipError("ssd_stream_create: %s" % lib().ssd_last_error().decode())
     st = torch.cuda.ExternalStream(h)
-    st._ssd_handle = h          # ExternalStream does not own the native stream: free_stream() destroys it
+    st._ssd_high_priority = hp
     return st
 
 
 def free_stream(st):
-    """Destroy a stream made by ``new_stream`` (idempotent).  The caller guarantees that nothing is queued on it
-    any more (``st.synchronize()`` first when in doubt)."""
-    h = getattr(st, "_ssd_handle", None)
-    if h:
-        st._ssd_handle = None
-        try:
-            lib().ssd_stream_destroy(vp(h))
-        except Exception:
-            pass
+    """Return a stream made by ``new_stream`` to the pool (idempotent per stream object)."""
+    hp = getattr(st, "_ssd_high_priority", None)
+    if hp is None or any(st is q for q in _stream_pool[hp]):
+        return
+    _stream_pool[hp].append(st)
 
 
 def to_dev(x, dtype=torch.float32):
