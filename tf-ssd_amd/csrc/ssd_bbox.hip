@@ -133,7 +133,40 @@ __global__ void decode_kernel(const float4* __restrict__ priors, const float4* _
 // its own row (row stride L words: conflict-free for odd L such as 21).
 // Candidates (score > thr, strict) are appended to the per-(image,class) list with one
 // atomic each; the later sort makes the result independent of the append order.
-template <bool DECODE>
+// softmax of one row in place (models/header.py:66 `Activation("softmax")`): THE definition of the net's class
+// probabilities -- softmax_kernel (ssd_net_forward's output) and the fused compact kernel of ssd_net_predict both call
+// it from this translation unit, so the two paths produce the same bits
+__device__ __forceinline__ void softmax_row(float* row, const int L) {
+    float mx = row[0];
+    for (int c = 1; c < L; ++c) mx = fmaxf(mx, row[c]);
+    float s = 0.f;
+    for (int c = 0; c < L; ++c) {
+        const float ev = expf(row[c] - mx);
+        row[c] = ev;
+        s += ev;
+    }
+    for (int c = 0; c < L; ++c) row[c] = row[c] / s;
+}
+
+// 256 rows per block staged through LDS (coalesced in/out); one lane per row.
+__global__ __launch_bounds__(256) void softmax_kernel(const float* __restrict__ in, const long rows,
+                                                      const int L, float* __restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) float tile[];
+    const long r0 = (long)blockIdx.x * 256;
+    const int nrows = (int)min((long)256, rows - r0);
+    const int n = nrows * L;
+    const float* src = in + r0 * L;
+    for (int e = threadIdx.x; e < n; e += 256) tile[e] = src[e];
+    __syncthreads();
+    if ((int)threadIdx.x < nrows) softmax_row(tile + threadIdx.x * L, L);
+    __syncthreads();
+    float* dst = out + r0 * L;
+    for (int e = threadIdx.x; e < n; e += 256) dst[e] = tile[e];
+}
+
+// LOGITS (ssd_net_predict): `probs` holds the head convs' LOGITS; the softmax runs on the LDS-staged slab right here
+// (no separate softmax pass over the [B, N, L] buffer, no launch); needs use_lds.
+template <bool DECODE, bool LOGITS>
 __global__ __launch_bounds__(256) void compact_kernel(
     const float4* __restrict__ deltas, const float* __restrict__ probs,
     const float4* __restrict__ priors, const float4 var, const int N, const int L,
@@ -152,6 +185,7 @@ __global__ __launch_bounds__(256) void compact_kernel(
     const int t = threadIdx.x;
     if (t >= rows) return;
     const int i = i0 + t;
+    if (LOGITS) softmax_row(tile + t * L, L);
     const float* row = use_lds ? (tile + t * L) : (src + (size_t)t * L);
     bool masked = false;
     if (DECODE) {
@@ -224,7 +258,7 @@ __device__ void block_sort_asc(K* keys, const int n) {
 constexpr int kSortLds = 4096;   // candidates sorted in LDS (32 KB); above: in place in HBM
 
 __global__ __launch_bounds__(256) void nms_class_kernel(
-    unsigned long long* __restrict__ cand_keys, const int* __restrict__ cand_count,
+    unsigned long long* __restrict__ cand_keys, int* __restrict__ cand_count,
     const float4* __restrict__ boxes, const int N, const int L, const int cap, const int maxk,
     const float iou_thr, unsigned long long* __restrict__ kept_keys, int* __restrict__ kept_count) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -238,6 +272,10 @@ __global__ __launch_bounds__(256) void nms_class_kernel(
     const int b = bc / L, c = bc - b * L;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n = min(cand_count[bc], cap);
+    // every thread has read the count: its (image, class) owner resets it, so the NEXT call on this workspace starts from
+    // zero without a memset launch (the net's predict path; a caller-owned workspace is still zeroed by the launcher)
+    __syncthreads();
+    if (tid == 0) cand_count[bc] = 0;
     if (n == 0) {
         if (tid == 0) kept_count[bc] = 0;
         return;
@@ -501,11 +539,15 @@ static int check_nms_args(int B, int N, int L, int max_per_class, int max_total)
 }
 
 // Shared driver: DECODE=true -> SSDDecoder path; false -> raw combined NMS.
+// flags (the net's own predict path): kNmsLogits -- `scores` holds logits, softmax fused into the compaction;
+// kNmsCountsClean -- the workspace's candidate counters are known to be zero (zeroed at allocation, re-zeroed by
+// nms_class_kernel of the previous call): no memset launch
+enum { kNmsLogits = 1, kNmsCountsClean = 2 };
 static int run_nms(bool decode, const float* deltas, const float* scores, const float* priors_or_boxes,
                    const float* var, int B, int N, int L, int max_per_class, int max_total,
                    float iou_thr, float score_thr, int clip, float* boxes_out, float* labels_out,
                    float* scores_out, int* valid_out, int* kept_idx, void* ws, size_t ws_bytes,
-                   hipStream_t st) {
+                   hipStream_t st, int flags = 0) {
     int rc = check_nms_args(B, N, L, max_per_class, max_total);
     if (rc) return rc;
     if (B == 0) return SSD_OK;
@@ -526,17 +568,27 @@ static int run_nms(bool decode, const float* deltas, const float* scores, const 
     SSD_CHECK_ARG(ws_bytes >= w.bytes, "decode_nms: workspace %zu < required %zu", ws_bytes, w.bytes);
     SSD_CHECK_ARG(((uintptr_t)ws & 15) == 0, "decode_nms: workspace must be 16-byte aligned");
 
-    SSD_HIP(hipMemsetAsync(w.cand_count, 0, (size_t)B * L * 4, st));
+    if (!(flags & kNmsCountsClean)) SSD_HIP(hipMemsetAsync(w.cand_count, 0, (size_t)B * L * 4, st));
     const float4 v4 = var ? make_float4(var[0], var[1], var[2], var[3]) : make_float4(1, 1, 1, 1);
     const size_t tile_bytes = (size_t)256 * L * 4;
     const int use_lds = tile_bytes <= 96 * 1024;
+    SSD_CHECK_ARG(!(flags & kNmsLogits) || (decode && use_lds), "decode_nms: fused softmax needs the LDS-staged decoder path");
+    if (tile_bytes > 64 * 1024 && use_lds) {
+        SSD_HIP(hipFuncSetAttribute((const void*)compact_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tile_bytes));
+        SSD_HIP(hipFuncSetAttribute((const void*)compact_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tile_bytes));
+        SSD_HIP(hipFuncSetAttribute((const void*)compact_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tile_bytes));
+    }
     dim3 grid(cdiv(N, 256), B);
-    if (decode) {
-        hipLaunchKernelGGL(compact_kernel<true>, grid, dim3(256), use_lds ? tile_bytes : 0, st,
+    if (decode && (flags & kNmsLogits)) {
+        hipLaunchKernelGGL((compact_kernel<true, true>), grid, dim3(256), tile_bytes, st,
+                           (const float4*)deltas, scores, (const float4*)priors_or_boxes, v4, N, L,
+                           score_thr, use_lds, w.boxes, w.cand_keys, w.cand_count, N);
+    } else if (decode) {
+        hipLaunchKernelGGL((compact_kernel<true, false>), grid, dim3(256), use_lds ? tile_bytes : 0, st,
                            (const float4*)deltas, scores, (const float4*)priors_or_boxes, v4, N, L,
                            score_thr, use_lds, w.boxes, w.cand_keys, w.cand_count, N);
     } else {
-        hipLaunchKernelGGL(compact_kernel<false>, grid, dim3(256), use_lds ? tile_bytes : 0, st,
+        hipLaunchKernelGGL((compact_kernel<false, false>), grid, dim3(256), use_lds ? tile_bytes : 0, st,
                            (const float4*)nullptr, scores, (const float4*)nullptr, v4, N, L,
                            score_thr, use_lds, (float4*)nullptr, w.cand_keys, w.cand_count, N);
     }
@@ -555,6 +607,22 @@ static int run_nms(bool decode, const float* deltas, const float* scores, const 
                        merge_hdr + (merge_lds_ok ? merge_keys : 0), st, w.kept_keys, w.kept_count,
                        nms_boxes, N, L, maxk, max_total, clip, merge_lds_ok, w.merge_ws,
                        (float4*)boxes_out, labels_out, scores_out, valid_out, kept_idx);
+    SSD_LAUNCH_CHECK();
+    return SSD_OK;
+}
+
+// The net's own predict path (csrc/ssd_net.hip): head LOGITS in, softmax fused into the compaction, no counter memset.
+// `ws` is the net's workspace, zeroed at allocation.  Returns SSD_E_UNSUPPORTED when the fused form cannot run (L too
+// large for the LDS-staged slab): the caller then runs the softmax layer + ssd_decode_nms.
+bool decode_nms_fused_ok(int L) { return (size_t)256 * L * 4 <= 96 * 1024; }
+int decode_nms_fused(const float* deltas, const float* logits, const float* priors, const float* var, int B, int N, int L,
+                     int max_per_class, int max_total, float iou_thr, float score_thr, float* boxes, float* labels,
+                     float* scores, int* valid, void* ws, size_t ws_bytes, hipStream_t st) {
+    return run_nms(true, deltas, logits, priors, var, B, N, L, max_per_class, max_total, iou_thr, score_thr, 1, boxes,
+                   labels, scores, valid, nullptr, ws, ws_bytes, st, kNmsLogits | kNmsCountsClean);
+}
+int launch_softmax_lds(const float* in, long rows, int L, float* out, hipStream_t st) {
+    hipLaunchKernelGGL(softmax_kernel, dim3(cdiv(rows, 256)), dim3(256), (size_t)256 * L * 4, st, in, rows, L, out);
     SSD_LAUNCH_CHECK();
     return SSD_OK;
 }

@@ -84,6 +84,7 @@ struct ssd_net {
     int num_priors = 0;
     bool finalized = false;
     bool fuse_blocks = true;        // run eligible inverted-residual blocks as one fused kernel
+    bool fuse_softmax = true;       // ssd_net_predict: the softmax runs inside the decoder's compaction kernel (csrc/ssd_bbox.hip) instead of as a pass of its own
     bool fuse_dwproj = true;        // ... and depthwise + project of the others as one kernel
     bool use_wino = true;           // offer the Winograd F(2x2,3x3) kernels to the autotune
     int precision = 0;              // 0: fp32 results everywhere (the reference's arithmetic); 1: "bf16" -- every matrix operand of the dense / 1x1 convs rounded once to bf16, one bf16 MFMA per product, fp32 accumulation and epilogues (BASELINE.json configs[3] / [4])

@@ -1105,8 +1105,18 @@ int ssd_net_feature_map_size(const ssd_net* net, int level) {
     return (net && level >= 0 && level < (int)net->fmap.size()) ? net->fmap[level] : 0;
 }
 
+// (csrc/ssd_bbox.hip) the decoder with the softmax fused into its compaction kernel: head LOGITS in
+namespace ssd {
+bool decode_nms_fused_ok(int L);
+int decode_nms_fused(const float* deltas, const float* logits, const float* priors, const float* var, int B, int N, int L,
+                     int max_per_class, int max_total, float iou_thr, float score_thr, float* boxes, float* labels,
+                     float* scores, int* valid, void* ws, size_t ws_bytes, hipStream_t st);
+}
+
+// logits_only: the softmax layer is left out (ssd_net_predict: the decoder's compaction kernel applies it on its
+// LDS-staged slab); probs_out then holds the head convs' logits
 static int forward_impl(ssd_net* net, const float* image_dev, int B, float* deltas_out, float* probs_out,
-                        hipStream_t st) {
+                        hipStream_t st, bool logits_only = false) {
     SSD_CHECK_ARG(net != nullptr, "ssd_net_forward: net is NULL");
     if (!net->finalized) {
         set_error("ssd_net_forward: call ssd_net_finalize() first");
@@ -1235,7 +1245,7 @@ static int forward_impl(ssd_net* net, const float* image_dev, int B, float* delt
     for (size_t oi = 0; oi < order.size(); ++oi) {
         const int i = (int)order[oi];
         Layer& l = net->layers[i];
-        if (layer_runs(*net, l)) {
+        if (layer_runs(*net, l) && !(logits_only && l.kind == LK_SOFTMAX)) {
             hipStream_t ls = stream_of(i);
             if (overlap) {
                 if (l.kind == LK_SOFTMAX) {        // join before the softmax
@@ -1315,6 +1325,7 @@ int ssd_net_predict(ssd_net* net, const float* image_dev, int B, const float* pr
         net->nms_ws = nullptr;
         net->nms_ws_bytes = 0;
         SSD_HIP(hipMalloc(&net->nms_ws, need));
+        SSD_HIP(hipMemset(net->nms_ws, 0, need));      // candidate counters start at zero and are re-zeroed by every call (nms_class_kernel)
         net->nms_ws_bytes = need;
     }
     hipStream_t st = (hipStream_t)stream;
@@ -1326,9 +1337,15 @@ int ssd_net_predict(ssd_net* net, const float* image_dev, int B, const float* pr
                                     (const void*)(intptr_t)B, (const void*)(intptr_t)max_total,
                                     (const void*)k1.i, (const void*)k2.i, (const void*)2};
     for (int i = 0; i < 4; ++i) { union { float f; intptr_t i; } k{}; k.f = v4[i]; key.push_back((const void*)k.i); }
+    // softmax folded into the decoder's compaction (one pass over the [B, N, L] buffer and two launches -- softmax, counter
+    // memset -- less); option "fuse_softmax" 0 keeps the layer-by-layer form
+    const bool fused_sm = net->fuse_softmax && decode_nms_fused_ok(L) && N >= 1;
     int rc = run_graphed(net, key, st, [&]() {
-        int r = forward_impl(net, image_dev, B, net->deltas, net->probs, st);
+        int r = forward_impl(net, image_dev, B, net->deltas, net->probs, st, fused_sm);
         if (r) return r;
+        if (fused_sm)
+            return decode_nms_fused(net->deltas, net->probs, priors_dev, v4, B, N, L, max_total, max_total, iou_thr, score_thr,
+                                    boxes_dev, labels_dev, scores_dev, valid_dev, net->nms_ws, net->nms_ws_bytes, st);
         return ssd_decode_nms(net->deltas, net->probs, priors_dev, v4, B, N, L, max_total, max_total, iou_thr,
                               score_thr, boxes_dev, labels_dev, scores_dev, valid_dev, nullptr, net->nms_ws,
                               net->nms_ws_bytes, (void*)st);
@@ -1435,6 +1452,11 @@ int ssd_net_set_option(ssd_net* net, const char* name, int value) {
     }
     if (std::string(name) == "image_ticket") {
         net->image_ticket = value != 0;
+        net->drop_graphs();
+        return SSD_OK;
+    }
+    if (std::string(name) == "fuse_softmax") {   // ssd_net_predict: softmax inside the decoder's compaction kernel (default 1)
+        net->fuse_softmax = value != 0;
         net->drop_graphs();
         return SSD_OK;
     }

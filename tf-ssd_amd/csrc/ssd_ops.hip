@@ -173,32 +173,8 @@ int launch_l2norm(const float* in, long pixels, int C, const float* gamma, float
 }
 
 // ------------------------------------------------------------------ softmax over the last dim
-// 256 rows per block staged through LDS (coalesced in/out); one lane per row.
-__global__ __launch_bounds__(256) void softmax_kernel(const float* __restrict__ in, const long rows,
-                                                      const int L, float* __restrict__ out) {
-    extern __shared__ __attribute__((aligned(16))) float tile[];
-    const long r0 = (long)blockIdx.x * 256;
-    const int nrows = (int)min((long)256, rows - r0);
-    const int n = nrows * L;
-    const float* src = in + r0 * L;
-    for (int e = threadIdx.x; e < n; e += 256) tile[e] = src[e];
-    __syncthreads();
-    if ((int)threadIdx.x < nrows) {
-        float* row = tile + threadIdx.x * L;
-        float mx = row[0];
-        for (int c = 1; c < L; ++c) mx = fmaxf(mx, row[c]);
-        float s = 0.f;
-        for (int c = 0; c < L; ++c) {
-            const float ev = expf(row[c] - mx);
-            row[c] = ev;
-            s += ev;
-        }
-        for (int c = 0; c < L; ++c) row[c] = row[c] / s;
-    }
-    __syncthreads();
-    float* dst = out + r0 * L;
-    for (int e = threadIdx.x; e < n; e += 256) dst[e] = tile[e];
-}
+// (the LDS-staged kernel lives in ssd_bbox.hip beside the fused decoder, which shares its row function: same bits)
+int launch_softmax_lds(const float* in, long rows, int L, float* out, hipStream_t st);
 
 __global__ void softmax_direct_kernel(const float* __restrict__ in, const long rows, const int L,
                                       float* __restrict__ out) {
@@ -216,7 +192,7 @@ int launch_softmax(const float* in, long rows, int L, float* out, hipStream_t st
     if (rows == 0) return SSD_OK;
     const size_t lds = (size_t)256 * L * 4;
     if (lds <= 64 * 1024) {
-        hipLaunchKernelGGL(softmax_kernel, dim3(cdiv(rows, 256)), dim3(256), lds, st, in, rows, L, out);
+        return launch_softmax_lds(in, rows, L, out, st);
     } else {
         const int blocks = (int)(cdiv(rows, 256) < 4096 ? cdiv(rows, 256) : 4096);
         hipLaunchKernelGGL(softmax_direct_kernel, dim3(blocks), dim3(256), 0, st, in, rows, L, out);
