@@ -322,6 +322,35 @@ def test_two_lanes_match_one_lane():
             np.testing.assert_array_equal(a.cpu().numpy(), b)
 
 
+def test_predict_fused_softmax_matches_the_layered_decoder_across_batch_sizes():
+    """``ssd_net_predict`` folds the softmax into the decoder's compaction kernel and keeps its candidate counters zero
+    between calls without a memset (csrc/ssd_bbox.hip): bitwise the detections of forward (softmax layer) +
+    ``SSDDecoder`` for a sequence of DIFFERENT batch sizes on one net (the workspace is carved once, for max_batch --
+    a per-call layout once let a small batch's kept counts land on a larger batch's candidate counters), and with the
+    option off."""
+    from models.decoder import SSDDecoder
+    from models.ssd_mobilenet_v2 import get_model
+    from utils import bbox_utils
+    hp = helpers.hyper_params("mobilenet_v2")
+    w = helpers.synthetic_weights("mobilenet_v2", hp)
+    m = get_model(hp, max_batch=6)
+    m.set_weights(w)
+    priors = bbox_utils.generate_prior_boxes(hp["feature_map_shapes"], hp["aspect_ratios"])
+    dec = SSDDecoder(priors, hp["variances"])
+    x = helpers.images(6, 300, seed=11)
+    for fuse in (1, 0, 1):
+        m.set_option("fuse_softmax", fuse)
+        for B in (6, 2, 5, 1, 6, 3):
+            b, l, s, v = [_np(t) for t in m.predict_on_device(x[:B], priors, hp["variances"])]
+            d, p = m(x[:B])
+            rb, rl, rs = [_np(t) for t in dec([d, p])]
+            assert (s > 0).sum() > 0
+            np.testing.assert_array_equal(s, rs)
+            np.testing.assert_array_equal(l, rl)
+            np.testing.assert_array_equal(b, rb)
+            np.testing.assert_array_equal(v, _np(dec.last_valid_detections))
+
+
 def test_lanes_hint_changes_only_the_summation_grouping():
     """With N lanes in flight the whole-image blocks split an image's expanded channels over fewer workgroups
     (option lanes_hint: B x groups x lanes fills the CUs).  The lanes' results are bitwise those of a single net

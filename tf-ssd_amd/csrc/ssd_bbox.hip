@@ -547,7 +547,7 @@ static int run_nms(bool decode, const float* deltas, const float* scores, const 
                    const float* var, int B, int N, int L, int max_per_class, int max_total,
                    float iou_thr, float score_thr, int clip, float* boxes_out, float* labels_out,
                    float* scores_out, int* valid_out, int* kept_idx, void* ws, size_t ws_bytes,
-                   hipStream_t st, int flags = 0) {
+                   hipStream_t st, int flags = 0, int ws_batch = 0) {
     int rc = check_nms_args(B, N, L, max_per_class, max_total);
     if (rc) return rc;
     if (B == 0) return SSD_OK;
@@ -564,7 +564,11 @@ static int run_nms(bool decode, const float* deltas, const float* scores, const 
     SSD_UNSUPPORTED_IF(nms_lds > 160 * 1024, "decode_nms: max_per_class=%d needs %zu B of LDS",
                        max_per_class, nms_lds);
     SSD_CHECK_ARG(ws != nullptr, "decode_nms: workspace is NULL");
-    NmsWs w = carve_ws(ws, B, N, L, maxk);
+    // the workspace is carved for ws_batch images when given (>= B): with kNmsCountsClean the counters have to sit at the
+    // same place whatever batch a call runs (a layout carved for a smaller B would put its kept counts where a larger
+    // batch's candidate counters live)
+    SSD_CHECK_ARG(ws_batch == 0 || ws_batch >= B, "decode_nms: workspace carved for %d images, batch %d", ws_batch, B);
+    NmsWs w = carve_ws(ws, ws_batch ? ws_batch : B, N, L, maxk);
     SSD_CHECK_ARG(ws_bytes >= w.bytes, "decode_nms: workspace %zu < required %zu", ws_bytes, w.bytes);
     SSD_CHECK_ARG(((uintptr_t)ws & 15) == 0, "decode_nms: workspace must be 16-byte aligned");
 
@@ -617,9 +621,9 @@ static int run_nms(bool decode, const float* deltas, const float* scores, const 
 bool decode_nms_fused_ok(int L) { return (size_t)256 * L * 4 <= 96 * 1024; }
 int decode_nms_fused(const float* deltas, const float* logits, const float* priors, const float* var, int B, int N, int L,
                      int max_per_class, int max_total, float iou_thr, float score_thr, float* boxes, float* labels,
-                     float* scores, int* valid, void* ws, size_t ws_bytes, hipStream_t st) {
+                     float* scores, int* valid, void* ws, size_t ws_bytes, int ws_batch, hipStream_t st) {
     return run_nms(true, deltas, logits, priors, var, B, N, L, max_per_class, max_total, iou_thr, score_thr, 1, boxes,
-                   labels, scores, valid, nullptr, ws, ws_bytes, st, kNmsLogits | kNmsCountsClean);
+                   labels, scores, valid, nullptr, ws, ws_bytes, st, kNmsLogits | kNmsCountsClean, ws_batch);
 }
 int launch_softmax_lds(const float* in, long rows, int L, float* out, hipStream_t st) {
     hipLaunchKernelGGL(softmax_kernel, dim3(cdiv(rows, 256)), dim3(256), (size_t)256 * L * 4, st, in, rows, L, out);

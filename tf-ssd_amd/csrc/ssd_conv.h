@@ -166,6 +166,13 @@ int launch_maxpool(const float* in, int B, int H, int W, int C, int k, int strid
                    int Ho, int Wo, float* out, hipStream_t st);
 int launch_l2norm(const float* in, long pixels, int C, const float* gamma, float* out, hipStream_t st);
 int launch_softmax(const float* in, long rows, int L, float* out, hipStream_t st);
+// (csrc/ssd_bbox.hip) the SSDDecoder with the softmax fused into its compaction kernel: head LOGITS in; `ws` is a
+// workspace of ssd_decode_nms_workspace_bytes(ws_batch, ...) -- carved for ws_batch >= B images whatever B a call runs --
+// whose candidate counters are zero (zeroed once at allocation; every call leaves them zero again)
+bool decode_nms_fused_ok(int L);
+int decode_nms_fused(const float* deltas, const float* logits, const float* priors, const float* var, int B, int N, int L,
+                     int max_per_class, int max_total, float iou_thr, float score_thr, float* boxes, float* labels,
+                     float* scores, int* valid, void* ws, size_t ws_bytes, int ws_batch, hipStream_t st);
 int launch_pack_weights(const float* hwio, int K, int Cout, int Kpad, int Npad, float* packed, hipStream_t st);
 // packed fp32 weights + room for their four bf16 planes (conv_split_planes points at them)
 inline size_t conv_packed_floats(int K, int Cout) {

@@ -707,6 +707,7 @@ ssd_net* ssd_net_create(int backbone, int img_size, int levels, const int* n_ars
             net->graphs_unsafe = true;
         }
     if (const char* g = getenv("SSD_TAIL_PRIO")) net->tail_prio = atoi(g) < 0 ? 0 : (atoi(g) > 2 ? 2 : atoi(g));    // diagnostics
+    if (const char* g = getenv("SSD_FUSE_SOFTMAX")) net->fuse_softmax = atoi(g) != 0;    // diagnostics (A/B of the decoder tail)
     if (const char* g = getenv("SSD_HIP_USE_GRAPH")) {      // diagnostics: pin the launch mode (0 direct, 1 graph replay)
         net->use_graph = atoi(g) != 0 && !net->graphs_unsafe;
         net->use_graph_auto = false;
@@ -1105,14 +1106,6 @@ int ssd_net_feature_map_size(const ssd_net* net, int level) {
     return (net && level >= 0 && level < (int)net->fmap.size()) ? net->fmap[level] : 0;
 }
 
-// (csrc/ssd_bbox.hip) the decoder with the softmax fused into its compaction kernel: head LOGITS in
-namespace ssd {
-bool decode_nms_fused_ok(int L);
-int decode_nms_fused(const float* deltas, const float* logits, const float* priors, const float* var, int B, int N, int L,
-                     int max_per_class, int max_total, float iou_thr, float score_thr, float* boxes, float* labels,
-                     float* scores, int* valid, void* ws, size_t ws_bytes, hipStream_t st);
-}
-
 // logits_only: the softmax layer is left out (ssd_net_predict: the decoder's compaction kernel applies it on its
 // LDS-staged slab); probs_out then holds the head convs' logits
 static int forward_impl(ssd_net* net, const float* image_dev, int B, float* deltas_out, float* probs_out,
@@ -1327,6 +1320,7 @@ int ssd_net_predict(ssd_net* net, const float* image_dev, int B, const float* pr
         SSD_HIP(hipMalloc(&net->nms_ws, need));
         SSD_HIP(hipMemset(net->nms_ws, 0, need));      // candidate counters start at zero and are re-zeroed by every call (nms_class_kernel)
         net->nms_ws_bytes = need;
+        net->nms_ws_batch = net->max_batch;
     }
     hipStream_t st = (hipStream_t)stream;
     SSD_CHECK_ARG(var != nullptr, "ssd_net_predict: variances pointer is NULL");
@@ -1339,13 +1333,13 @@ int ssd_net_predict(ssd_net* net, const float* image_dev, int B, const float* pr
     for (int i = 0; i < 4; ++i) { union { float f; intptr_t i; } k{}; k.f = v4[i]; key.push_back((const void*)k.i); }
     // softmax folded into the decoder's compaction (one pass over the [B, N, L] buffer and two launches -- softmax, counter
     // memset -- less); option "fuse_softmax" 0 keeps the layer-by-layer form
-    const bool fused_sm = net->fuse_softmax && decode_nms_fused_ok(L) && N >= 1;
+    const bool fused_sm = net->fuse_softmax && decode_nms_fused_ok(L) && N >= 1 && net->nms_ws_batch >= B;
     int rc = run_graphed(net, key, st, [&]() {
         int r = forward_impl(net, image_dev, B, net->deltas, net->probs, st, fused_sm);
         if (r) return r;
         if (fused_sm)
             return decode_nms_fused(net->deltas, net->probs, priors_dev, v4, B, N, L, max_total, max_total, iou_thr, score_thr,
-                                    boxes_dev, labels_dev, scores_dev, valid_dev, net->nms_ws, net->nms_ws_bytes, st);
+                                    boxes_dev, labels_dev, scores_dev, valid_dev, net->nms_ws, net->nms_ws_bytes, net->nms_ws_batch, st);
         return ssd_decode_nms(net->deltas, net->probs, priors_dev, v4, B, N, L, max_total, max_total, iou_thr,
                               score_thr, boxes_dev, labels_dev, scores_dev, valid_dev, nullptr, net->nms_ws,
                               net->nms_ws_bytes, (void*)st);
@@ -1458,6 +1452,11 @@ int ssd_net_set_option(ssd_net* net, const char* name, int value) {
     if (std::string(name) == "fuse_softmax") {   // ssd_net_predict: softmax inside the decoder's compaction kernel (default 1)
         net->fuse_softmax = value != 0;
         net->drop_graphs();
+        // the layer-by-layer decoder carves the workspace per call: back to all-zero counters for the fused form
+        if (net->nms_ws) {
+            (void)hipDeviceSynchronize();
+            SSD_HIP(hipMemset(net->nms_ws, 0, net->nms_ws_bytes));
+        }
         return SSD_OK;
     }
     if (std::string(name) == "fuse_dwproj") {
