@@ -79,6 +79,7 @@ def main():
     ap.add_argument("--no-overlap", action="store_true", help="profiling runs: no intra-step side streams (option overlap_heads 0), so per-kernel durations are uncontended")
     ap.add_argument("--layers", action="store_true", help="also print the per-layer table to stderr")
     ap.add_argument("--train", action="store_true", help="time the training step (SURVEY 8f N1) instead of inference")
+    ap.add_argument("--h2d", action="store_true", help="also time the K steps fed from pinned HOST batches (PCIe-inclusive, separately labelled)")
     ap.add_argument("--dtype", default="f32", choices=["f32", "bf16"],
                     help="f32 (default: the reference's arithmetic, BASELINE configs[1] / [2]) or bf16 (configs[3] / [4]: every matrix "
                          "operand of the dense / 1x1 convs rounded once to bf16, one bf16 MFMA per product, fp32 accumulation "
@@ -229,6 +230,38 @@ def main():
     valid = decoder_model.decoder.last_valid_detections
     mean_det = float(valid.float().mean().item())
 
+    # ---- separately labelled (never `value`): the same K steps fed from PINNED HOST batches -- every step's 4 B S S 3
+    # bytes cross PCIe inside the timed region, copied by the lane's own stream beside the other lanes' kernels
+    # (DecoderModel.submit of an ssd_hip.pinned_empty buffer); what a predictor.py-style caller with host data gets
+    h2d = None
+    if args.h2d and args.lanes > 1:
+        hosts = []
+        for k in range(args.lanes + 1):
+            hb = ssd_hip.pinned_empty((B, hp["img_size"], hp["img_size"], 3))
+            hb.copy_(x.cpu() if k == 0 else torch.from_numpy(data_utils.synthetic_images(B, hp["img_size"], seed=100 + rank + k)))
+            hosts.append(hb)
+
+        def h2d_steps(n):
+            for i in range(n):
+                decoder_model.submit(hosts[i % len(hosts)])
+            decoder_model.wait()
+
+        h2d_steps(2 * args.lanes)
+        rs = []
+        for _ in range(3):
+            torch.cuda.synchronize()
+            barrier()
+            t0 = time.perf_counter()
+            h2d_steps(args.steps)
+            torch.cuda.synchronize()
+            barrier()
+            rs.append(reduce_max(time.perf_counter() - t0))
+        e = sorted(rs)[1]
+        h2d = {"mode": "pinned host batches, H2D copy on each lane's stream inside the timed region (PCIe-inclusive)",
+               "ms_per_step": 1e3 * e / args.steps, "images_per_sec": world * B * args.steps / e,
+               "bytes_per_step": 4 * B * hp["img_size"] * hp["img_size"] * 3,
+               "h2d_GB_per_s": 4e-9 * B * hp["img_size"] * hp["img_size"] * 3 * args.steps / e}
+
     # ---- roofline leg: same K steps with per-layer hipEvents on the launch stream
     model.set_timing(True)
     for _ in range(args.steps):
@@ -326,6 +359,7 @@ def main():
                                                             world * B * args.steps / min(regions)]},
         # informational: the same K steps in the OTHER launch mode (see --lanes)
         "other_mode": other,
+        "h2d_overlapped_predict": h2d,
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,

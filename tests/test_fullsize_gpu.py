@@ -456,3 +456,37 @@ def test_predict_ascending_batch_sizes():
     assert (eight[2] > 0).sum() > 0
     for a, b in zip(back, [r[:1] for r in eight]):              # same tiles at any batch? at least close
         assert np.abs(a - b).max() <= 1e-4
+
+
+def test_pinned_host_batches_through_the_lanes():
+    """``DecoderModel.submit`` of a pinned host batch (``ssd_hip.pinned_empty``): the H2D copy runs on the lane's own
+    stream in front of its step; results are bitwise those of the resident-input path, also when a pinned buffer is
+    reused for later steps and when the batch is smaller than the lane's buffer."""
+    import ssd_hip as h
+    from models.decoder import get_decoder_model
+    from models.ssd_mobilenet_v2 import get_model
+    from utils import bbox_utils
+    hp = helpers.hyper_params("mobilenet_v2")
+    w = helpers.synthetic_weights("mobilenet_v2", hp)
+    m = get_model(hp, max_batch=6)
+    m.set_weights(w)
+    priors = bbox_utils.generate_prior_boxes(hp["feature_map_shapes"], hp["aspect_ratios"])
+    dm1 = get_decoder_model(m, priors, hp, lanes=1)
+    dm3 = get_decoder_model(m, priors, hp, lanes=3)
+    batches = [helpers.images(6 if i != 3 else 4, 300, seed=70 + i) for i in range(7)]
+    ref = [tuple(t.cpu().numpy() for t in dm1(b)) for b in batches]
+    hosts = []
+    for b in batches:
+        hb = h.pinned_empty(b.shape)
+        hb.numpy()[...] = b
+        hosts.append(hb)
+    outs = [dm3.submit(hb) for hb in hosts]
+    dm3.wait()
+    torch.cuda.synchronize()
+    for o, r in zip(outs, ref):
+        for a, b in zip(o, r):
+            np.testing.assert_array_equal(a.cpu().numpy(), b)
+    # predict() over an iterable of pinned batches
+    p = dm3.predict(hosts)
+    for k in range(3):
+        np.testing.assert_array_equal(p[k], np.concatenate([r[k] for r in ref], 0))

@@ -229,6 +229,9 @@ __device__ __forceinline__ void conv_mfma_body(const ConvParams& p, float* __res
 #pragma unroll
     for (int kc = 0; kc < BK / 16; ++kc)
         fcol[kc] = SWZ ? (((kc * 4 + (lane >> 4)) ^ (BK == 32 ? (frow >> 1) & 7 : frow)) << 2) : kc * 16 + fk;
+#ifndef SSD_C3_VARIANT
+#define SSD_C3_VARIANT 0      // experiments (tools/r4/build_c3var.sh + tests/micro/conv3_variants.py); 0 = the production kernel
+#endif
 #ifndef SSD_C3_ABLATE
 #define SSD_C3_ABLATE 0       // diagnostics (tests/micro/conv3_ablate.py): 1 no MFMA, 2 no fragment reads, 4 no split, 8 no global loads, 16 no LDS stores
 #endif
@@ -303,8 +306,33 @@ __device__ __forceinline__ void conv_mfma_body(const ConvParams& p, float* __res
 #pragma unroll
                 for (int pl = 0; pl < NP; ++pl) b[mi].p[pl] = *reinterpret_cast<const bf16x8*>(r + pl * BM * 64);
             }
+#if SSD_C3_VARIANT & 1
+            // variant 1: two weight fragments at a time -> 2 * MT independent accumulator chains per product term (the
+            // per-accumulator order of the six terms is unchanged: same bits)
+            constexpr int NT2 = (NP == 3) ? (NT & ~1) : 0;
 #pragma unroll
-            for (int ni = 0; ni < NT; ++ni) {
+            for (int ni = 0; ni < NT2; ni += 2) {
+                const char* r0 = Wb + ((wn * NT + ni) * 16 + frow) * 64 + fq;
+                BP<NP> a0, a1;
+#pragma unroll
+                for (int pl = 0; pl < NP; ++pl) {
+                    a0.p[pl] = *reinterpret_cast<const bf16x8*>(r0 + pl * BN * 64);
+                    a1.p[pl] = *reinterpret_cast<const bf16x8*>(r0 + 16 * 64 + pl * BN * 64);
+                }
+                constexpr int TW[6] = {1, 0, 2, 0, 1, 0}, TX[6] = {1, 2, 0, 1, 0, 0};
+#pragma unroll
+                for (int t = 0; t < 6; ++t)
+#pragma unroll
+                    for (int mi = 0; mi < MT; ++mi) {
+                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0.p[TW[t]], b[mi].p[TX[t]], acc[mi][ni], 0, 0, 0);
+                        acc[mi][ni + 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1.p[TW[t]], b[mi].p[TX[t]], acc[mi][ni + 1], 0, 0, 0);
+                    }
+            }
+#else
+            constexpr int NT2 = 0;
+#endif
+#pragma unroll
+            for (int ni = NT2; ni < NT; ++ni) {
                 const char* r = Wb + ((wn * NT + ni) * 16 + frow) * 64 + fq;
                 BP<NP> a;
 #pragma unroll

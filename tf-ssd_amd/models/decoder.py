@@ -89,6 +89,7 @@ class DecoderModel(object):
         self.lanes = max(1, int(lanes))
         self._lane_models = []
         self._lane_streams = []
+        self._lane_inputs = {}             # lane -> device buffer for pinned host batches (submit)
         self._lane_version = None
         self._next_lane = 0
         self._lanes_calibrated = False
@@ -221,19 +222,36 @@ class DecoderModel(object):
         if self.lanes == 1 or not hasattr(self.base_model, "predict_on_device"):
             return self(images)
         d = self.decoder
-        x = _h.to_dev(images)
+        # a PINNED host batch (torch CPU tensor, ``ssd_hip.pinned_empty``) is copied by the lane itself: the H2D DMA is
+        # queued on the lane's stream in front of its step, so it runs beside the other lanes' kernels and the host
+        # never blocks (pageable arrays take the synchronous staged copy of ``to_dev`` on the caller's stream)
+        pinned = isinstance(images, torch.Tensor) and images.device.type == "cpu" and images.is_pinned() \
+            and images.dtype == torch.float32 and images.is_contiguous()
+        x = images if pinned else _h.to_dev(images)
         self.base_model._ensure(x.shape[0])            # the replicas inherit the base model's kernel table
         if self.lanes >= 2 and not self._lanes_calibrated:
             for k in range(self.lanes):
                 self._lane(k)
+            xcal = _h.to_dev(x) if pinned else x          # (the one-off lane check runs on a resident copy)
             if self.calibrate and self.lanes == 2:
-                self._calibrate_lane_streams(x)
+                self._calibrate_lane_streams(xcal)
             else:
-                self._check_lanes_pay(x)
+                self._check_lanes_pay(xcal)
         i = (self._next_lane % self.lanes) if getattr(self, "_lanes_active", True) else 0
         self._next_lane += 1
         m, st = self._lane(i)
-        if sync_input:
+        if pinned:
+            # per-lane device buffer: the copy of step n + lanes into it is ordered behind step n's kernels on the same stream
+            buf = self._lane_inputs.get(i)
+            if buf is None or buf.shape[0] < x.shape[0] or buf.shape[1:] != x.shape[1:]:
+                buf = torch.empty((max(x.shape[0], getattr(self.base_model, "_max_batch", 0) or 0),) + tuple(x.shape[1:]),
+                                  dtype=torch.float32, device=_h.device())
+                self._lane_inputs[i] = buf
+            with torch.cuda.stream(st):
+                xd = buf[:x.shape[0]]
+                xd.copy_(x, non_blocking=True)
+            x = xd
+        elif sync_input:
             st.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(st):
             b, l, s, v = m.predict_on_device(x, d.prior_boxes, d.variances, max_total=d.max_total_size,
@@ -253,6 +271,7 @@ class DecoderModel(object):
             _h.free_stream(st)
         self._lane_streams = []
         self._lane_models = []
+        self._lane_inputs = {}
         self._lanes_calibrated = False
 
     def __del__(self):

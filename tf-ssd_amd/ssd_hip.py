@@ -206,6 +206,14 @@ def to_dev(x, dtype=torch.float32):
     return torch.as_tensor(np.ascontiguousarray(np.asarray(x)), dtype=dtype).to(dev).contiguous()
 
 
+def pinned_empty(shape, dtype=torch.float32):
+    """A page-locked host tensor (``t.numpy()`` is a zero-copy NumPy view to fill): batches handed to
+    ``DecoderModel.submit`` / ``predict`` in such buffers are copied to the GPU by the lane's own stream (asynchronous DMA
+    beside the other lanes' kernels) instead of through the staged, blocking copy pageable memory takes."""
+    device()
+    return torch.empty(tuple(shape), dtype=dtype, pin_memory=True)
+
+
 def ptr(t):
     return vp(t.data_ptr()) if t is not None else vp(0)
 

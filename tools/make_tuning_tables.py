@@ -25,9 +25,11 @@ for p in (REPO, os.path.join(REPO, "tf-ssd_amd"), os.path.join(REPO, "tests")):
 
 # BASELINE.json configs (C2 B=64, C3 VGG B=32, C4 per-GPU B=32, C5 512^2 B=16), their neighbours, and the
 # batch sizes the GPU tests / smoke / bench's CPU-sample legs finalize at
-DEFAULT_SHAPES = [("mobilenet_v2", 300, b) for b in (1, 2, 3, 4, 5, 8, 16, 24, 32, 64, 128, 232, 256)] + \
-                 [("vgg16", 300, b) for b in (1, 2, 8, 16, 32)] + \
-                 [("mobilenet_v2", 512, b) for b in (1, 16)]
+DEFAULT_SHAPES = [("mobilenet_v2", 300, b, "fp32") for b in (1, 2, 3, 4, 5, 6, 8, 16, 24, 32, 64, 128, 232, 256)] + \
+                 [("vgg16", 300, b, "fp32") for b in (1, 2, 3, 6, 8, 16, 32)] + \
+                 [("mobilenet_v2", 512, b, "fp32") for b in (1, 16)] + \
+                 [("mobilenet_v2", 300, b, "bf16") for b in (4, 64)] + [("mobilenet_v2", 512, 16, "bf16")] + \
+                 [("vgg16", 300, b, "bf16") for b in (8, 32)]      # the bf16 mode (BASELINE configs[3] / [4]): its tests' and bench shapes
 
 
 def majority(tables):
@@ -58,9 +60,9 @@ def generate(args):
     if args.shapes:
         shapes = []
         for s in args.shapes:
-            bb, sz, b = s.split(":")
-            shapes.append((bb, int(sz), int(b)))
-    for bb, S, B in shapes:
+            parts = s.split(":")
+            shapes.append((parts[0], int(parts[1]), int(parts[2]), parts[3] if len(parts) > 3 else "fp32"))
+    for bb, S, B, prec in shapes:
         hp = helpers.hyper_params(bb)
         if S == 512:
             hp["img_size"] = 512
@@ -68,7 +70,7 @@ def generate(args):
         w = helpers.synthetic_weights(bb, hp)
         tabs = []
         for r in range(args.repeats):
-            m = SSDModel(bb, hp, max_batch=B)
+            m = SSDModel(bb, hp, max_batch=B, precision=prec)
             m.set_weights(w)
             m.set_tuning("")                   # nothing preset: time everything
             m._ensure(B)
@@ -77,7 +79,7 @@ def generate(args):
             torch.cuda.empty_cache()
         table = majority(tabs)
         agree = sum(t == tabs[0] for t in tabs)
-        key = tuning.table_key(bb, S, hp["total_labels"], hp["aspect_ratios"], B)
+        key = tuning.table_key(bb, S, hp["total_labels"], hp["aspect_ratios"], B) + ("" if prec == "fp32" else "_" + prec)
         with open(os.path.join(args.out, key + ".tune"), "w") as f:
             f.write(tuning.with_header(table, key=key, build=build, device=dev, repeats=args.repeats,
                                        version=ssd_hip.lib().ssd_version().decode().replace(" ", "_")))
@@ -91,7 +93,7 @@ def adopt(args):
     for f in sorted(os.listdir(args.adopt)):
         if not f.endswith(".tune"):
             continue
-        m = re.match(r"^((?:mobilenet_v2|vgg16)_\d+_\d+_a[\d-]+_b\d+)(?:_.*)?\.tune$", f)
+        m = re.match(r"^((?:mobilenet_v2|vgg16)_\d+_\d+_a[\d-]+_b\d+(?:_bf16)?)(?:_.*)?\.tune$", f)
         if not m or "=" in f:                       # tables of non-default option sets are not shipped
             continue
         text = open(os.path.join(args.adopt, f)).read()
@@ -107,7 +109,7 @@ if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--out", default=os.path.join(REPO, "gpurun_out", "tables"))
     ap.add_argument("--repeats", type=int, default=3)
-    ap.add_argument("--shapes", nargs="*", help="backbone:size:batch ...")
+    ap.add_argument("--shapes", nargs="*", help="backbone:size:batch[:bf16] ...")
     ap.add_argument("--adopt")
     a = ap.parse_args()
     adopt(a) if a.adopt else generate(a)
