@@ -92,6 +92,7 @@ struct DwProjParams {
     int kpad_p, npad_p;
     int tiles_y, tiles_x;       // filled by the launcher
     int ablate;                 // diagnostics (SSD_DWPROJ_ABLATE): 1 skip depthwise math, 2 skip MFMAs, 4 skip chunk loads
+    int bf16;                   // the net's precision-1 mode: project on the bf16 matrix cores (operands rounded once, fp32 accumulation)
 };
 bool dwproj_supported(const DwProjParams& p);
 int launch_dwproj(DwProjParams p, hipStream_t st);

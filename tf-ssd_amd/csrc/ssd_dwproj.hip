@@ -22,6 +22,7 @@
 // output channels (gridDim.y): each half recomputes the (cheap, VALU) depthwise.
 #include <cstdlib>
 
+#include "ssd_bf16x3.h"
 #include "ssd_conv.h"
 
 namespace ssd {
@@ -257,7 +258,11 @@ __global__ __launch_bounds__(256) void dwproj_kernel(const DwProjParams p) {
 //   consumers, iteration i:  acc += Ds[i&1] x Ws[i&1]
 // (a phase ablation of the 4-wave kernel showed its depthwise, MFMA and staging times simply add
 // up: 6.4 + 8.5 + 4.3 us of a 33 us block_7 launch, 10.9 + 20.4 + 9.7 of 55 us for block_11.)
-template <int S, int TH, int TW, int SL, int WM, int WN, int NTW, int NOPS>
+// BF16 (the net's precision-1 mode): the project runs on the bf16 matrix cores -- the consumer waves round their D and
+// Wp fragments (fp32 in LDS, as the producers wrote them) to bf16 on the fly, 8 k-values per lane, and issue TWO
+// v_mfma_f32_16x16x32_bf16 per (pixel group, output tile) and 48-channel chunk (k 0-31, k 32-47 + zeros) instead of
+// twelve v_mfma_f32_16x16x4_f32; depthwise, BatchNorm shifts, ReLU6 and the residual add stay fp32.
+template <int S, int TH, int TW, int SL, int WM, int WN, int NTW, int NOPS, bool BF16 = false>
 __global__ __launch_bounds__(512) void dwproj8_kernel(const DwProjParams p) {
     using Sh = DwProjShape<S, TH, TW, SL, WM, WN, NTW>;
     constexpr int PT = Sh::PT, PG = Sh::PG, MTW = Sh::MTW, NTB = Sh::NTB, IW = Sh::IW, HP = Sh::HP, kLD = Sh::LD;
@@ -418,6 +423,34 @@ __global__ __launch_bounds__(512) void dwproj8_kernel(const DwProjParams p) {
     for (int i = 0; i < nchunks; ++i) {
         const float* D = Ds + (i & 1) * DS;
         const float* W = Ws + (i & 1) * WS;
+        if constexpr (BF16) {
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                const int k0 = ks * 32 + (lane >> 4) * 8;
+                const bool ok = k0 < kCK;                  // second step: k 32..47 live in lanes g4 < 2, the rest multiply zeros
+                const int kk = ok ? k0 : 0;
+                BP<1> a[NTW], bb[MTW];
+                const f32x4 z = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int ni = 0; ni < NTW; ++ni) {
+                    const float* r = W + ((wn * NTW + ni) * 16 + frow) * kLD + kk;
+                    const f32x4 lo = *reinterpret_cast<const f32x4*>(r), hi = *reinterpret_cast<const f32x4*>(r + 4);
+                    a[ni] = splitN<1>(ok ? lo : z, ok ? hi : z);
+                }
+#pragma unroll
+                for (int mi = 0; mi < MTW; ++mi) {
+                    const float* r = D + ((wm * MTW + mi) * 16 + frow) * kLD + kk;
+                    const f32x4 lo = *reinterpret_cast<const f32x4*>(r), hi = *reinterpret_cast<const f32x4*>(r + 4);
+                    bb[mi] = splitN<1>(ok ? lo : z, ok ? hi : z);
+                }
+#pragma unroll
+                for (int mi = 0; mi < MTW; ++mi)
+#pragma unroll
+                    for (int ni = 0; ni < NTW; ++ni) acc[mi][ni] = mmaN<1>(a[ni], bb[mi], acc[mi][ni]);
+            }
+            lds_barrier();
+            continue;
+        }
 #pragma unroll
         for (int kc = 0; kc < ((p.ablate & 2) ? 0 : kCK / 16); ++kc) {
             f32x4 a[NTW], bb[MTW];
@@ -467,12 +500,14 @@ struct DwProjCfg {
     dwproj_fn fn;
     size_t lds8;
     dwproj_fn fn8[4];       // s_nop 0 (none) / 3 / 5 / 6 after each consumer MFMA
+    dwproj_fn fn8b;         // the project on the bf16 matrix cores (precision 1)
 };
 #define DCFG(S, TH, TW, SL, WM, WN, NTW, CMIN, CMAX, NSPLIT)                                               \
     {S, CMIN, CMAX, TH, TW, NTW * WN, NSPLIT, DwProjShape<S, TH, TW, SL, WM, WN, NTW>::lds_floats * 4,       \
      dwproj_kernel<S, TH, TW, SL, WM, WN, NTW>, DwProjShape<S, TH, TW, SL, WM, WN, NTW>::lds_floats * 8,      \
      {dwproj8_kernel<S, TH, TW, SL, WM, WN, NTW, 0>, dwproj8_kernel<S, TH, TW, SL, WM, WN, NTW, 3>,              \
-      dwproj8_kernel<S, TH, TW, SL, WM, WN, NTW, 5>, dwproj8_kernel<S, TH, TW, SL, WM, WN, NTW, 6>}}
+      dwproj8_kernel<S, TH, TW, SL, WM, WN, NTW, 5>, dwproj8_kernel<S, TH, TW, SL, WM, WN, NTW, 6>},              \
+     dwproj8_kernel<S, TH, TW, SL, WM, WN, NTW, 0, true>}
 const DwProjCfg kDwProj[] = {
     // stride 1, 19-wide row bands (blocks 7-12 of SSD300): 6 pixel groups x Cout/16 tiles on 2x2 waves
     DCFG(1, 5, 19, 5, 2, 2, 2, 1, 64, 1),
@@ -512,7 +547,7 @@ int launch_dwproj(DwProjParams p, hipStream_t st) {
     static const int waves = getenv("SSD_DWPROJ_WAVES") ? atoi(getenv("SSD_DWPROJ_WAVES")) : 8;     // diagnostics knob
     static const int nopsel = getenv("SSD_DWPROJ_NOP") ? atoi(getenv("SSD_DWPROJ_NOP")) & 3 : 0;     // diagnostics knob
     if (waves == 8 && c->lds8 <= 160 * 1024) {
-        dwproj_fn fn8 = c->fn8[nopsel];
+        dwproj_fn fn8 = p.bf16 ? c->fn8b : c->fn8[nopsel];
         SSD_HIP(hipFuncSetAttribute((const void*)fn8, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds8));
         hipLaunchKernelGGL(fn8, dim3((unsigned)tiles, c->n_split), dim3(512), c->lds8, st, p);
         SSD_LAUNCH_CHECK();

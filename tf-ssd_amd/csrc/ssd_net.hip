@@ -382,6 +382,7 @@ static DwProjParams dwproj_params(const ssd_net& net, const Layer& f, int B) {
     p.Ho = f.Ho; p.Wo = f.Wo; p.stride = f.stride; p.pad_t = f.pt; p.pad_l = f.pl;
     p.kpad_p = conv_kpad(lp.Cin);
     p.npad_p = conv_npad(lp.Cout);
+    p.bf16 = net.precision;
     return p;
 }
 
@@ -1552,7 +1553,7 @@ const char* ssd_net_layer_config(const ssd_net* net, int i) {
     if (l.kind == LK_FUSED) {        // which fused kernel family runs the block (bench.py prices each at its matrix instruction)
         if (!layer_runs(*net, l)) return "";
         if (l.f_type == 1) return "stem";
-        if (l.f_type == 2) return "dwproj";
+        if (l.f_type == 2) return net->precision ? "dwproj_bf16" : "dwproj";
         const FusedBlockParams p = fused_params(*net, l, 1);
         if (!fused_block_supported(p)) return net->precision ? "image_bf16" : "image";
         if (net->fuse_band == 2 && p.we3 && band3_block_supported(p)) return net->precision ? "band_bf16" : "band3";
