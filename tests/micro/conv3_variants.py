@@ -9,10 +9,18 @@ import subprocess
 import sys
 
 REPO = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-SHAPES = [("mbv2 head1", 64, 19, 576, 100, 3, "mfma3_2x7_8x1", 5), ("mbv2 head2", 64, 10, 1280, 150, 3, "mfma3_4x5_4x2", 10),
-          ("mbv2 Conv_1", 64, 10, 320, 1280, 1, "mfma3_4x4_2x4", 1), ("mbv2 extra1_1", 64, 10, 1280, 256, 1, "mfma3_4x4_2x4", 5),
-          ("vgg conv4_2", 32, 38, 512, 512, 3, "mfma3_4x4_4x2", 1), ("vgg conv3_2", 32, 75, 256, 256, 3, "mfma3_4x4_4x2", 1),
-          ("vgg conv2_2", 32, 150, 128, 128, 3, "mfma3_4x4_4x2", 1), ("vgg fc7", 32, 19, 1024, 1024, 1, "mfma3_4x4_4x2", 1)]
+SHAPES = [("mbv2 head1", 64, 19, 576, 100, 3, "mfma3_2x7_8x1", 5), ("mbv2 head1", 64, 19, 576, 100, 3, "mfma3_2x7_4x1", 3),
+          ("mbv2 head1", 64, 19, 576, 100, 3, "mfma3_2x7_4x1", 2),
+          ("mbv2 head2", 64, 10, 1280, 150, 3, "mfma3_4x5_4x2", 10), ("mbv2 head2", 64, 10, 1280, 150, 3, "mfma3_4x5_2x2", 5),
+          ("mbv2 head2", 64, 10, 1280, 150, 3, "mfma3_2x5_2x2", 5),
+          ("mbv2 Conv_1", 64, 10, 320, 1280, 1, "mfma3_4x4_2x4", 1), ("mbv2 Conv_1", 64, 10, 320, 1280, 1, "mfma3_4x4_2x2", 1),
+          ("mbv2 extra1_1", 64, 10, 1280, 256, 1, "mfma3_4x4_2x4", 5), ("mbv2 extra1_1", 64, 10, 1280, 256, 1, "mfma3_4x4_2x2", 3),
+          ("vgg conv4_2", 32, 38, 512, 512, 3, "mfma3_4x4_4x2", 1), ("vgg conv4_2", 32, 38, 512, 512, 3, "mfma3_4x4_2x2", 1),
+          ("vgg conv4_2", 32, 38, 512, 512, 3, "mfma3_2x4_2x2", 1),
+          ("vgg conv3_2", 32, 75, 256, 256, 3, "mfma3_4x4_4x2", 1), ("vgg conv3_2", 32, 75, 256, 256, 3, "mfma3_4x4_2x2", 1),
+          ("vgg conv2_2", 32, 150, 128, 128, 3, "mfma3_4x4_4x2", 1), ("vgg conv2_2", 32, 150, 128, 128, 3, "mfma3_4x4_2x2", 1),
+          ("vgg conv1_2", 32, 300, 64, 64, 3, "mfma3_4x2_4x2", 1), ("vgg conv1_2", 32, 300, 64, 64, 3, "mfma3_4x2_2x2", 1),
+          ("vgg fc7", 32, 19, 1024, 1024, 1, "mfma3_4x4_4x2", 1), ("vgg fc7", 32, 19, 1024, 1024, 1, "mfma3_4x4_2x2", 1)]
 
 
 def child():

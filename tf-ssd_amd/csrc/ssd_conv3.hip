@@ -45,7 +45,12 @@ const Conv3Cfg kCfg3[] = {
     C3CFG(4, 5, 4, 2),    // 256 x 160
 };
 constexpr int kNumCfg3 = sizeof(kCfg3) / sizeof(kCfg3[0]);
-int c3_lds_bytes(const Conv3Cfg& g, int planes) { return 2 * planes * (g.BM + g.BN) * 64; }
+int c3_lds_bytes(const Conv3Cfg& g, int planes) {
+#if SSD_C3_VARIANT & 2
+    if (g.threads == 256) return planes * (g.BM + g.BN) * 64;       // experiment: one LDS stage for the 4-wave tiles
+#endif
+    return 2 * planes * (g.BM + g.BN) * 64;
+}
 
 // four bf16 planes behind the packed fp32 weights: h, m, l (the exact split, x = h + m + l) and r = the bf16 rounding of
 // x (round to nearest even) for the one-product bf16 kernels

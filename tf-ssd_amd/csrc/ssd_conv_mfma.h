@@ -364,6 +364,22 @@ __device__ __forceinline__ void conv_mfma_body(const ConvParams& p, float* __res
             }
         }
         __syncthreads();
+#if SSD_C3_VARIANT & 2
+        // variant 2 (4-wave tiles): ONE LDS stage, two barriers per K tile -- half the LDS, so two or three workgroups
+        // share a CU and fill each other's barrier / staging phases (instead of the in-workgroup double buffer)
+        if constexpr (NTHR == 256) {
+            for (int kt = kt_begin; kt < kt_end; ++kt) {
+                mma_tile(0);
+                __syncthreads();
+                if (kt + 1 < kt_end) store3(0, xs0, ws0, vm0);
+                if (kt + 2 < kt_end) {
+                    tile_advance();
+                    load3(xs0, ws0, vm0);
+                }
+                __syncthreads();
+            }
+        } else
+#endif
         for (int kt = kt_begin; kt < kt_end; ++kt) {
             const int stage = (kt - kt_begin) & 1;
             if (!late) mma_tile(stage);
@@ -532,8 +548,13 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvParams p) {
 }
 
 // split-bf16 variant: dynamic LDS, 2 * 3 * 16 * (MT*WM + NT*WN) * 64 bytes
+#if SSD_C3_VARIANT & 2
+#define SSD_C3_BOUNDS(WM, WN) __launch_bounds__(64 * WM * WN, (WM * WN == 4) ? ((SSD_C3_VARIANT & 4) ? 3 : 2) : 1)
+#else
+#define SSD_C3_BOUNDS(WM, WN) __launch_bounds__(64 * WM * WN)
+#endif
 template <int MT, int NT, int WM, int WN, bool GEMM1X1>
-__global__ __launch_bounds__(64 * WM * WN) void conv_mfma3_kernel(const ConvParams p) {
+__global__ SSD_C3_BOUNDS(WM, WN) void conv_mfma3_kernel(const ConvParams p) {
     extern __shared__ __attribute__((aligned(16))) float smem3[];
     conv_mfma_body<MT, NT, WM, WN, 32, GEMM1X1, 3>(p, smem3);
 }
