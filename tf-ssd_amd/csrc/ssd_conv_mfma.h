@@ -363,7 +363,61 @@ __device__ __forceinline__ void conv_mfma_body(const ConvParams& p, float* __res
                 load3(xs0, ws0, vm0);
             }
         }
+#if SSD_C3_VARIANT & 8
+        // variant 8: the PIXELS (streamed from HBM / the Infinity Cache: the long latency) are fetched TWO K tiles ahead into
+        // two register sets, the weight planes (L2-resident) stay one tile ahead.  Set A holds tile kt + 1 and set B tile
+        // kt + 2 when an even iteration starts; the loop is unrolled by two so that both sets are named statically.
+        {
+            f32x4 xsB[XP];
+            unsigned vmB = 0;
+            auto loadX = [&](f32x4 (&X)[XP], unsigned& vm) {
+                vm = 0;
+#pragma unroll
+                for (int ps = 0; ps < XP; ++ps) {
+                    const bool ok = x_is_valid(ps);
+                    vm |= (ok ? 1u : 0u) << ps;
+                    if (GEMM1X1) {
+                        X[ps] = f32x4{0.f, 0.f, 0.f, 0.f};
+                        if (ok) X[ps] = *reinterpret_cast<const f32x4*>(xrow1[ps] + l_k0);
+                    } else {
+                        X[ps] = *reinterpret_cast<const f32x4*>(xbase + (unsigned)(ok ? xoff[ps] + l_xtile : 0));
+                    }
+                }
+            };
+            auto loadW = [&](bf16x8 (&W)[WP3], int k0) {
+#pragma unroll
+                for (int ps = 0; ps < WP3; ++ps) W[ps] = *reinterpret_cast<const bf16x8*>(w3base + w3off[ps] + k0);
+            };
+            // state here: tile kt_begin stored in stage 0; (xs0, ws0) hold tile kt_begin + 1 (if any), l_* describe it
+            int k0_next = l_k0;                          // k offset of the tile whose WEIGHTS are loaded next (tile kt + 2)
+            if (kt_begin + 2 < kt_end) {
+                tile_advance();
+                k0_next = l_k0;
+                loadX(xsB, vmB);                         // pixels of tile kt_begin + 2
+            }
+            __syncthreads();
+            auto step = [&](int kt, f32x4 (&XA)[XP], unsigned& vmA) {      // XA holds tile kt + 1; refilled with tile kt + 3
+                const int stage = (kt - kt_begin) & 1;
+                if (!late) mma_tile(stage);
+                if (kt + 1 < kt_end) store3(stage ^ 1, XA, ws0, vmA);
+                if (kt + 2 < kt_end) loadW(ws0, k0_next);                  // weights of tile kt + 2
+                if (kt + 3 < kt_end) {
+                    tile_advance();
+                    k0_next = l_k0;
+                    loadX(XA, vmA);                                        // pixels of tile kt + 3
+                }
+                if (late) mma_tile(stage);
+                __syncthreads();
+            };
+            for (int kt = kt_begin; kt < kt_end; kt += 2) {
+                step(kt, xs0, vm0);
+                if (kt + 1 < kt_end) step(kt + 1, xsB, vmB);
+            }
+        }
+        if (false)
+#else
         __syncthreads();
+#endif
 #if SSD_C3_VARIANT & 2
         // variant 2 (4-wave tiles): ONE LDS stage, two barriers per K tile -- half the LDS, so two or three workgroups
         // share a CU and fill each other's barrier / staging phases (instead of the in-workgroup double buffer)
