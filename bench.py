@@ -79,7 +79,8 @@ def main():
     ap.add_argument("--no-overlap", action="store_true", help="profiling runs: no intra-step side streams (option overlap_heads 0), so per-kernel durations are uncontended")
     ap.add_argument("--layers", action="store_true", help="also print the per-layer table to stderr")
     ap.add_argument("--train", action="store_true", help="time the training step (SURVEY 8f N1) instead of inference")
-    ap.add_argument("--h2d", action="store_true", help="also time the K steps fed from pinned HOST batches (PCIe-inclusive, separately labelled)")
+    ap.add_argument("--no-h2d", dest="h2d", action="store_false",
+                    help="skip the separately labelled leg that feeds the K steps from pinned HOST batches (PCIe-inclusive; never `value`)")
     ap.add_argument("--dtype", default="f32", choices=["f32", "bf16"],
                     help="f32 (default: the reference's arithmetic, BASELINE configs[1] / [2]) or bf16 (configs[3] / [4]: every matrix "
                          "operand of the dense / 1x1 convs rounded once to bf16, one bf16 MFMA per product, fp32 accumulation "
@@ -514,7 +515,9 @@ def train_bench(args, hp, get_model, rank, world, dist):
                                    "; fp32 instead of bf16" if args.dtype == "f32" else ""),
                    "global_batch": world * B, "parallelism": "batch-DP x%d, RCCL all-reduce of %d fp32 gradients" % (
                        world, ssd_hip.lib().ssd_net_trainable_floats(model._net)),
-                   "loss_first_step": first, "loss_last_step": last},
+                   "loss_first_step": first, "loss_last_step": last,
+                   "conv_tiles": "cost model (SSD_HIP_TRAIN_AUTOTUNE=0)" if os.environ.get("SSD_HIP_TRAIN_AUTOTUNE") == "0"
+                                 else "timed on the device at the first step, kept for the process (csrc/ssd_train.hip pick_measured)"},
         # whole step against the fp32 MFMA peak (the convs the cost model hands to the split-bf16 tiles run above that
         # rate; the step is bound by the elementwise / BatchNorm passes)
         # `frac` = time the matrix cores would need at peak for the FLOPs the step issued (each family at the peak of

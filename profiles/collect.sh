@@ -11,7 +11,7 @@ cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 # one step at a time, no intra-step side streams, no second timing leg: every kernel runs alone, so the per-kernel
 # averages of the trace are uncontended and reproduce the bench line's per-layer hipEvent times
 # BENCH_ARGS: another configuration of the same command (e.g. "--backbone vgg16")
-CMD="python bench.py --steps 10 --warmup 3 --no-cpu-baseline --lanes 1 --no-overlap --no-other-leg $BENCH_ARGS"
+CMD="python bench.py --steps 10 --warmup 3 --no-cpu-baseline --lanes 1 --no-overlap --no-other-leg --no-h2d $BENCH_ARGS"
 # first run only fills the tuning cache, so that the profiled runs contain no autotune launches
 export SSD_HIP_TUNE_CACHE=$OUT/tune
 timeout 600 $CMD > $OUT/bench_plain.log 2>&1

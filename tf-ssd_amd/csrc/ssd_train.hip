@@ -16,6 +16,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstring>
+#include <map>
 
 #include "ssd_bf16x3.h"
 #include "ssd_net.h"
@@ -135,6 +136,7 @@ struct PackJob {
     const float* w2;
     float* dst;
     int mode, K, Cout, Cout1, Kpad, Npad, kh, kw, Ci, CoPad;
+    int bf16;       // the net's precision: 0 -> the planes h, m, l (split-bf16 tiles) are written, 1 -> only the rounding r (bf16 tiles)
 };
 __global__ __launch_bounds__(256) void pack_jobs_kernel(const PackJob* __restrict__ jobs) {
     const PackJob j = jobs[blockIdx.y];
@@ -156,13 +158,17 @@ __global__ __launch_bounds__(256) void pack_jobs_kernel(const PackJob* __restric
         j.dst[e] = v;
         // the same matrix as four bf16 planes behind the fp32 one: the exact split h, m, l (split-bf16 conv tiles,
         // ssd_conv3.hip) and the bf16 rounding r (bf16 tiles)
+        // (only the planes this precision's tiles read: the re-pack runs every step)
         short* pl = reinterpret_cast<short*>(j.dst + total);
-        short h, m, l;
-        split1(v, h, m, l);
-        pl[e] = h;
-        pl[total + e] = m;
-        pl[2 * total + e] = l;
-        pl[3 * total + e] = rne1(v);
+        if (j.bf16) {
+            pl[3 * total + e] = rne1(v);
+        } else {
+            short h, m, l;
+            split1(v, h, m, l);
+            pl[e] = h;
+            pl[total + e] = m;
+            pl[2 * total + e] = l;
+        }
     }
 }
 
@@ -860,6 +866,7 @@ struct TrainLayer {
 struct ssd_train_state {
     int batch = 0;
     size_t P = 0;
+    int precision = 0;                  // the net's precision the weight re-pack jobs were planned for
     double step_flops[3] = {0, 0, 0};   // matrix-core FLOPs of the last forward_backward: fp32-MFMA convs, split-bf16 convs, weight gradients
     float *flat = nullptr, *m = nullptr, *v = nullptr;
     std::vector<long> poff;             // parameter -> offset in the flat trainable vector (-1: not trainable)
@@ -1026,10 +1033,78 @@ static ConvParams dense_conv_params(int B, int H, int W, int Cin, int Cout, int 
 // [0] conv forward / backward-data on fp32-MFMA tiles, [1] on split-bf16 tiles, [2] weight gradients (fp32 MFMA)
 static thread_local double g_step_flops[3] = {0, 0, 0};
 
+// Tile choice of the training convs (forward and backward-data).  Default (SSD_HIP_TRAIN_AUTOTUNE unset or 1): the first
+// time a conv shape is seen every valid tile of the net's precision is TIMED on the device (into a scratch output: a
+// residual / accumulate-in-place epilogue must not run twice on the real tensor) and the fastest is kept for the process
+// (measured: MobileNetV2 B=32 12.42 -> 11.15 ms per step, bf16 11.69 -> 10.70, VGG16 B=16 31.0 -> 28.8: the cost model
+// favours large tiles that the short-K layers of a 32-image batch cannot fill).  Every step of a process runs the same
+// tiles; ACROSS processes the choice -- and with it the last bits of a step -- may differ with the box (training has no
+// bit-exactness contract; the inference path keeps its shipped tables).  SSD_HIP_TRAIN_AUTOTUNE=0: the cost model
+// (conv_pick_config: deterministic); =2 also prints what was found.
+struct TrainPickKey {
+    long M; int K, Cout, kh, kw, stride, dil, H, W, Cin, flags;
+    bool operator<(const TrainPickKey& o) const { return memcmp(this, &o, sizeof(*this)) < 0; }
+};
+static std::map<TrainPickKey, int>& train_picks() { static std::map<TrainPickKey, int> m; return m; }
+
+static int pick_measured(const ConvParams& p, hipStream_t st, int model_cfg, int verbose) {
+    TrainPickKey k{};
+    memset(&k, 0, sizeof(k));
+    k.M = p.M; k.K = p.K; k.Cout = p.Cout; k.kh = p.kh; k.kw = p.kw; k.stride = p.stride; k.dil = p.dil; k.H = p.H; k.W = p.W;
+    k.Cin = p.Cin;
+    k.flags = (p.residual ? 1 : 0) | (p.n_split ? 2 : 0) | (p.scale ? 4 : 0) | (p.shift ? 8 : 0) | (p.act << 4) | (p.bf16 << 8) |
+              (p.vec_store << 9);
+    auto it = train_picks().find(k);
+    if (it != train_picks().end()) return it->second;
+    float* scratch = nullptr;
+    const size_t out_floats = (size_t)p.M * (size_t)(p.out_pixel_stride > p.Cout ? p.out_pixel_stride : p.Cout) + 4096;
+    if (hipMalloc((void**)&scratch, out_floats * sizeof(float)) != hipSuccess) { (void)hipGetLastError(); return model_cfg; }
+    ConvParams q = p;
+    q.out = scratch;
+    if (q.n_split) { q.out2 = scratch; q.n_split = 0; }          // (timing only: one destination)
+    q.out_batch_stride = (long)p.Ho * p.Wo * q.out_pixel_stride;
+    hipEvent_t e0, e1;
+    (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+    int best = model_cfg;
+    float best_ms = 1e30f, model_ms = 0.f;
+    for (int c = 0; c < conv_num_configs(); ++c) {
+        if (!conv_config_valid(c, q) || !conv_config_allowed(c, q.bf16)) continue;
+        const char* cn = conv_config_name(c);
+        if (!strncmp(cn, "wino_", 5) || !strncmp(cn, "skinny_", 7) || (!strncmp(cn, "direct", 6) && c != model_cfg)) continue;
+        if (conv_launch(q, c, st)) { (void)hipGetLastError(); continue; }
+        float ms = 1e30f;
+        for (int trial = 0; trial < 3; ++trial) {
+            (void)hipEventRecord(e0, st);
+            for (int r = 0; r < 3; ++r) (void)conv_launch(q, c, st);
+            (void)hipEventRecord(e1, st);
+            (void)hipEventSynchronize(e1);
+            float t = 0.f;
+            (void)hipEventElapsedTime(&t, e0, e1);
+            ms = t < ms ? t : ms;
+            if (trial == 0 && ms > 2.0f * best_ms) break;
+        }
+        if (c == model_cfg) model_ms = ms;
+        if (ms < best_ms) { best_ms = ms; best = c; }
+    }
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    (void)hipFree(scratch);
+    if (verbose)
+        fprintf(stderr, "[ssd train tune] M=%ld K=%d N=%d k%dx%d s%d: model %s %.1f us -> %s %.1f us\n", p.M, p.K, p.Cout, p.kh, p.kw,
+                p.stride, conv_config_name(model_cfg), model_ms * 1000.f / 3, conv_config_name(best), best_ms * 1000.f / 3);
+    train_picks()[k] = best;
+    return best;
+}
+
 static int launch_conv(ConvParams& p, hipStream_t st) {
     p.vec_store = (((uintptr_t)p.out & 15) == 0) && (p.out_pixel_stride % 4 == 0) && (p.out_batch_stride % 4 == 0);
-    const int cfg = conv_pick_config(p);
+    int cfg = conv_pick_config(p);
     SSD_UNSUPPORTED_IF(cfg < 0, "train: no conv kernel for Cin=%d Cout=%d k=%dx%d", p.Cin, p.Cout, p.kh, p.kw);
+    static const int tune = getenv("SSD_HIP_TRAIN_AUTOTUNE") ? atoi(getenv("SSD_HIP_TRAIN_AUTOTUNE")) : 1;
+    if (tune) {
+        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+        (void)hipStreamIsCapturing(st, &cs);
+        if (cs == hipStreamCaptureStatusNone) cfg = pick_measured(p, st, cfg, tune > 1);
+    }
     const char* cn = conv_config_name(cfg);
     g_step_flops[(strncmp(cn, "mfma3_", 6) == 0 || strncmp(cn, "bf16_", 5) == 0) ? 1 : 0] += 2.0 * (double)p.M * p.K * p.Cout;
     return conv_launch(p, cfg, st);
@@ -1199,6 +1274,7 @@ int ssd_net_train_begin(ssd_net* net, int batch) {
         const TrainLayer& t = s->tl[i];
         if (!t.active || l.kind != LK_CONV) continue;
         PackJob j{};
+        j.bf16 = net->precision;
         j.w = s->flat + s->poff[l.p_kernel];
         j.w2 = l.p_kernel2 >= 0 ? s->flat + s->poff[l.p_kernel2] : nullptr;
         j.K = l.kh * l.kw * l.Cin;
@@ -1214,6 +1290,7 @@ int ssd_net_train_begin(ssd_net* net, int batch) {
         }
     }
     s->n_pack_jobs = (int)jobs.size();
+    s->precision = net->precision;
     if (!rc && !jobs.empty()) rc = talloc(*s, (jobs.size() * sizeof(PackJob) + 3) / 4, &s->pack_jobs);
     if (!rc) rc = talloc(*s, max_out, &s->scratch_dy);
     if (!rc) rc = talloc(*s, max_dz, &s->scratch_dz);
@@ -1287,6 +1364,10 @@ int ssd_net_train_forward_backward(ssd_net* net, const float* image_dev, int B, 
     if (!net->train) { set_error("ssd_net_train_forward_backward: call ssd_net_train_begin() first"); return SSD_E_STATE; }
     ssd_train_state& s = *net->train;
     SSD_CHECK_ARG(B >= 1 && B <= s.batch, "ssd_net_train_forward_backward: batch %d exceeds the planned %d", B, s.batch);
+    if (s.precision != net->precision) {
+        set_error("ssd_net_train_forward_backward: the precision option changed since ssd_net_train_begin (the weight re-pack was planned for %d): call ssd_net_train_begin again", s.precision);
+        return SSD_E_STATE;
+    }
     hipStream_t st = (hipStream_t)stream;
     const int N = net->num_priors, L = net->L;
     s.act[0] = const_cast<float*>(image_dev);
