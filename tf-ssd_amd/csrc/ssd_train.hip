@@ -1110,32 +1110,17 @@ static int launch_conv(ConvParams& p, hipStream_t st) {
     return conv_launch(p, cfg, st);
 }
 
-// dW [K][N] (row-major, = Keras HWIO) = im2col(X)^T * G
-static int wgrad(ssd_train_state& s, const Layer& l, int B, const float* x, const float* g, int ldg, int N, float* dW,
-                 hipStream_t st) {
+// dW [K][N] (row-major, = Keras HWIO) = im2col(X)^T * G with tile shape `cfg`
+static int wgrad_with(ssd_train_state& s, const Layer& l, int B, const float* x, const float* g, int ldg, int N, float* dW,
+                      hipStream_t st, const WgradCfg* cfg, bool count) {
     WgradParams p{};
     p.x = x; p.g = g;
     p.B = B; p.H = l.H; p.W = l.W; p.Cin = l.Cin; p.Ho = l.Ho; p.Wo = l.Wo;
     p.kh = l.kh; p.kw = l.kw; p.stride = l.stride; p.dil = l.dil; p.pad_t = l.pt; p.pad_l = l.pl;
     p.N = N; p.ldg = ldg; p.K = l.kh * l.kw * l.Cin;
     p.M = (long)B * l.Ho * l.Wo;
-    // Least padded tile area first (MFMA work); among equals the shape that stages the fewest floats per M
-    // row (every tile re-reads its 32-row slabs of X and G: ctiles * ntiles * (tc + tn)).  Measured: by
-    // staged floats alone 128 x 128 wins everywhere, +4 % on VGG16 (512-channel layers, no padding) but
-    // -3 % on MobileNetV2 (96 -> 576 expands padded to 128 x 640); the lexicographic rule keeps both.
     p.im2col = l.Cin % 4 != 0;            // RGB stems (Cin = 3): one tile spans all K = 27 rows instead of 3 of 16 per tap
     const int rows = p.im2col ? p.K : l.Cin;
-    const WgradCfg* cfg = &kWgrad[0];
-    {
-        long best_area = -1, best_staged = -1;
-        for (const auto& c : kWgrad) {
-            const long ct = (rows + c.tc - 1) / c.tc, nt = (N + c.tn - 1) / c.tn;
-            const long area = ct * c.tc * nt * c.tn, staged = ct * nt * (c.tc + c.tn);
-            if (best_area < 0 || area < best_area || (area == best_area && staged < best_staged)) {
-                best_area = area; best_staged = staged; cfg = &c;
-            }
-        }
-    }
     p.ctiles = (rows + cfg->tc - 1) / cfg->tc;
     p.ntiles = (N + cfg->tn - 1) / cfg->tn;
     p.vec_x = (l.Cin % 4 == 0) && (((uintptr_t)x & 15) == 0);
@@ -1155,8 +1140,72 @@ static int wgrad(ssd_train_state& s, const Layer& l, int B, const float* x, cons
     p.partial = s.partial;
     hipLaunchKernelGGL(cfg->fn, dim3((unsigned)tiles, (unsigned)chunks), dim3(256), 0, st, p);
     SSD_LAUNCH_CHECK();
-    g_step_flops[2] += 2.0 * (double)p.M * p.K * N;
+    if (count) g_step_flops[2] += 2.0 * (double)p.M * p.K * N;
     return chunk_sum(s.partial, chunks, (long)kn, dW, st);
+}
+
+// Tile shape of a weight gradient.  Heuristic: least padded tile area first (MFMA work); among equals the shape that
+// stages the fewest floats per M row (every tile re-reads its 32-row slabs of X and G: ctiles * ntiles * (tc + tn)).
+// Measured: by staged floats alone 128 x 128 wins everywhere, +4 % on VGG16 (512-channel layers, no padding) but -3 % on
+// MobileNetV2 (96 -> 576 expands padded to 128 x 640); the lexicographic rule keeps both.  With SSD_HIP_TRAIN_AUTOTUNE
+// (default on, see launch_conv) every shape of the table is timed the first time a layer is seen (dW is written, not
+// accumulated: running it repeatedly is harmless) and the fastest kept for the process.
+static int wgrad(ssd_train_state& s, const Layer& l, int B, const float* x, const float* g, int ldg, int N, float* dW,
+                 hipStream_t st) {
+    const bool im2col = l.Cin % 4 != 0;
+    const int rows = im2col ? l.kh * l.kw * l.Cin : l.Cin;
+    const WgradCfg* cfg = &kWgrad[0];
+    {
+        long best_area = -1, best_staged = -1;
+        for (const auto& c : kWgrad) {
+            const long ct = (rows + c.tc - 1) / c.tc, nt = (N + c.tn - 1) / c.tn;
+            const long area = ct * c.tc * nt * c.tn, staged = ct * nt * (c.tc + c.tn);
+            if (best_area < 0 || area < best_area || (area == best_area && staged < best_staged)) {
+                best_area = area; best_staged = staged; cfg = &c;
+            }
+        }
+    }
+    static const int tune = getenv("SSD_HIP_TRAIN_AUTOTUNE") ? atoi(getenv("SSD_HIP_TRAIN_AUTOTUNE")) : 1;
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    (void)hipStreamIsCapturing(st, &cs);
+    if (tune && cs == hipStreamCaptureStatusNone) {
+        TrainPickKey k{};
+        memset(&k, 0, sizeof(k));
+        k.M = (long)B * l.Ho * l.Wo; k.K = l.kh * l.kw * l.Cin; k.Cout = N; k.kh = l.kh; k.kw = l.kw; k.stride = l.stride;
+        k.dil = l.dil; k.H = l.H; k.W = l.W; k.Cin = l.Cin; k.flags = (1 << 20) | ldg;      // bit 20: a weight gradient
+        auto it = train_picks().find(k);
+        if (it != train_picks().end()) {
+            cfg = &kWgrad[it->second];
+        } else {
+            hipEvent_t e0, e1;
+            (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+            int best = (int)(cfg - kWgrad);
+            float best_ms = 1e30f, model_ms = 0.f;
+            for (int c = 0; c < (int)(sizeof(kWgrad) / sizeof(kWgrad[0])); ++c) {
+                if (wgrad_with(s, l, B, x, g, ldg, N, dW, st, &kWgrad[c], false)) { (void)hipGetLastError(); continue; }
+                float ms = 1e30f;
+                for (int trial = 0; trial < 3; ++trial) {
+                    (void)hipEventRecord(e0, st);
+                    for (int r = 0; r < 2; ++r) (void)wgrad_with(s, l, B, x, g, ldg, N, dW, st, &kWgrad[c], false);
+                    (void)hipEventRecord(e1, st);
+                    (void)hipEventSynchronize(e1);
+                    float t = 0.f;
+                    (void)hipEventElapsedTime(&t, e0, e1);
+                    ms = t < ms ? t : ms;
+                    if (trial == 0 && ms > 2.0f * best_ms) break;
+                }
+                if (&kWgrad[c] == cfg) model_ms = ms;
+                if (ms < best_ms) { best_ms = ms; best = c; }
+            }
+            (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+            if (tune > 1)
+                fprintf(stderr, "[ssd train tune] wgrad M=%ld K=%d N=%d: heuristic %dx%d %.1f us -> %dx%d %.1f us\n", k.M, k.K, N, cfg->tc,
+                        cfg->tn, model_ms * 500.f, kWgrad[best].tc, kWgrad[best].tn, best_ms * 500.f);
+            train_picks()[k] = best;
+            cfg = &kWgrad[best];
+        }
+    }
+    return wgrad_with(s, l, B, x, g, ldg, N, dW, st, cfg, true);
 }
 
 }  // namespace ssd
