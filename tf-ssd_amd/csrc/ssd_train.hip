@@ -876,6 +876,15 @@ struct ssd_train_state {
     std::vector<TrainLayer> tl;
     std::vector<float*> owned;
     float *scratch_dy = nullptr, *scratch_dz = nullptr, *scratch_w = nullptr, *partial = nullptr;
+    // weight gradients on a side stream beside the rest of the backward (dX chain, BatchNorm backward of the layers below):
+    // dY alternates between two buffers (a buffer is rewritten only after the weight gradient that reads it is done), the
+    // weight-gradient partial slab is its own
+    float* dy_buf[2] = {nullptr, nullptr};
+    float* partial_w = nullptr;
+    size_t partial_w_floats = 0;
+    hipStream_t wstream = nullptr;
+    hipEvent_t ev_dy = nullptr, ev_wdone[2] = {nullptr, nullptr}, ev_wall = nullptr;
+    bool wpending[2] = {false, false};
     float* pack_jobs = nullptr;  // device array of PackJob (one launch re-packs every conv weight)
     int n_pack_jobs = 0;
     size_t partial_floats = 0;
@@ -895,6 +904,9 @@ struct ssd_train_state {
 void ssd_train_state_free(ssd_train_state* s) {
     if (!s) return;
     for (auto e : s->bucket_ev)
+        if (e) (void)hipEventDestroy(e);
+    if (s->wstream) { (void)hipStreamSynchronize(s->wstream); (void)hipStreamDestroy(s->wstream); }
+    for (hipEvent_t e : {s->ev_dy, s->ev_wdone[0], s->ev_wdone[1], s->ev_wall})
         if (e) (void)hipEventDestroy(e);
     for (float* p : s->owned)
         if (p) (void)hipFree(p);
@@ -1134,14 +1146,19 @@ static int wgrad_with(ssd_train_state& s, const Layer& l, int B, const float* x,
         rpc *= 2;
         chunks = (p.M + rpc - 1) / rpc;
     }
-    int rc = ensure_partial(s, (size_t)chunks * kn);
-    if (rc) return rc;
+    if ((size_t)chunks * kn > s.partial_w_floats) {      // grow-only, own slab (weight gradients may run beside the reductions of the main chain)
+        float* np = nullptr;
+        int rca = talloc(s, (size_t)chunks * kn, &np);
+        if (rca) return rca;
+        s.partial_w = np;
+        s.partial_w_floats = (size_t)chunks * kn;
+    }
     p.rows_per_chunk = rpc;
-    p.partial = s.partial;
+    p.partial = s.partial_w;
     hipLaunchKernelGGL(cfg->fn, dim3((unsigned)tiles, (unsigned)chunks), dim3(256), 0, st, p);
     SSD_LAUNCH_CHECK();
     if (count) g_step_flops[2] += 2.0 * (double)p.M * p.K * N;
-    return chunk_sum(s.partial, chunks, (long)kn, dW, st);
+    return chunk_sum(s.partial_w, chunks, (long)kn, dW, st);
 }
 
 // Tile shape of a weight gradient.  Heuristic: least padded tile area first (MFMA work); among equals the shape that
@@ -1342,6 +1359,21 @@ int ssd_net_train_begin(ssd_net* net, int batch) {
     s->precision = net->precision;
     if (!rc && !jobs.empty()) rc = talloc(*s, (jobs.size() * sizeof(PackJob) + 3) / 4, &s->pack_jobs);
     if (!rc) rc = talloc(*s, max_out, &s->scratch_dy);
+    if (!rc) rc = talloc(*s, max_out, &s->dy_buf[1]);
+    s->dy_buf[0] = s->scratch_dy;
+    if (!rc && getenv("SSD_HIP_TRAIN_WGRAD_STREAM") && atoi(getenv("SSD_HIP_TRAIN_WGRAD_STREAM")) == 0) {
+        s->wstream = nullptr;                       // diagnostics: weight gradients in line on the caller's stream
+    } else if (!rc) {
+        if (hipStreamCreateWithFlags(&s->wstream, hipStreamNonBlocking) != hipSuccess ||
+            hipEventCreateWithFlags(&s->ev_dy, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&s->ev_wdone[0], hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&s->ev_wdone[1], hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&s->ev_wall, hipEventDisableTiming) != hipSuccess) {
+            (void)hipGetLastError();
+            set_error("ssd_net_train_begin: side stream / events for the weight gradients could not be created");
+            rc = SSD_E_HIP;
+        }
+    }
     if (!rc) rc = talloc(*s, max_dz, &s->scratch_dz);
     if (!rc) rc = talloc(*s, max_w, &s->scratch_w);
     if (!rc) rc = talloc(*s, maxC, &s->dgamma_tmp);
@@ -1508,8 +1540,32 @@ int ssd_net_train_forward_backward(ssd_net* net, const float* image_dev, int B, 
     std::fill(s.gwritten.begin(), s.gwritten.end(), 0);
     // gradient buckets: everything at or above `threshold` in the flat vector is final -> publish those buckets
     size_t next_bucket = s.bucket_lo.size();
+    // weight gradients run on the side stream (s.wstream) beside the rest of the backward; dY alternates between two buffers
+    int dy_cur = 0;
+    for (int k = 0; k < 2; ++k) s.wpending[k] = false;
+    auto acquire_dy = [&]() -> float* {      // next dY buffer: the main stream first waits for the weight gradient still reading it
+        dy_cur ^= 1;
+        if (s.wstream && s.wpending[dy_cur]) {
+            (void)hipStreamWaitEvent(st, s.ev_wdone[dy_cur], 0);
+            s.wpending[dy_cur] = false;
+        }
+        return s.dy_buf[dy_cur];
+    };
+    auto join_wgrads = [&]() -> int {        // everything issued on the side stream so far is ordered before what follows on st
+        if (!s.wstream) return SSD_OK;
+        SSD_HIP(hipEventRecord(s.ev_wall, s.wstream));
+        SSD_HIP(hipStreamWaitEvent(st, s.ev_wall, 0));
+        s.wpending[0] = s.wpending[1] = false;
+        return SSD_OK;
+    };
     auto mark_ready = [&](long threshold) -> int {
+        bool joined = false;
         while (next_bucket > 0 && s.bucket_lo[next_bucket - 1] >= threshold) {
+            if (!joined) {                   // a bucket is final only when the side stream's weight gradients in it are
+                const int rj = join_wgrads();
+                if (rj) return rj;
+                joined = true;
+            }
             if (getenv("SSD_HIP_DEBUG_BUCKETS")) fprintf(stderr, "[ssd] bucket %zu (lo %ld) final at threshold %ld\n", next_bucket - 1, s.bucket_lo[next_bucket - 1], threshold);
             SSD_HIP(hipEventRecord(s.bucket_ev[next_bucket - 1], st));
             --next_bucket;
@@ -1526,6 +1582,7 @@ int ssd_net_train_forward_backward(ssd_net* net, const float* image_dev, int B, 
         }
         const long M = (long)B * l.Ho * l.Wo;
         const float* x = s.act[l.in];
+        float* const dyb = (l.kind == LK_POOL) ? nullptr : acquire_dy();      // this layer's dY / scratch buffer
         if (l.kind == LK_POOL || l.kind == LK_L2NORM) {
             if (!s.gwritten[l.out]) {
                 set_error("train: no gradient reached tensor '%s'", net->tensors[l.out].name.c_str());
@@ -1543,10 +1600,10 @@ int ssd_net_train_forward_backward(ssd_net* net, const float* image_dev, int B, 
                 const long blocks = (M + 3) / 4;
                 hipLaunchKernelGGL(l2norm_bwd_kernel, dim3((unsigned)(blocks < 8192 ? blocks : 8192)), dim3(256), 0, st, x,
                                    s.gact[l.out], net->params[l.p_gamma].dev, M, l.Cin, s.gact[l.in], (int)s.gwritten[l.in],
-                                   s.scratch_dy);
+                                   dyb);
                 SSD_LAUNCH_CHECK();
                 RedParams rp{};
-                rp.a = s.scratch_dy; rp.M = M; rp.C = l.Cin; rp.lda = l.Cin;
+                rp.a = dyb; rp.M = M; rp.C = l.Cin; rp.lda = l.Cin;
                 long chunks = 0;
                 rc = col_reduce<RED_SUM>(s, rp, &chunks, st);
                 if (!rc) rc = col_finalize(s, chunks, l.Cin, 1.0f, grads_flat_dev + t.g_gamma, nullptr, 0, st);
@@ -1559,14 +1616,14 @@ int ssd_net_train_forward_backward(ssd_net* net, const float* image_dev, int B, 
         int ldy = l.Cout;
         if (l.head_kind) {
             ldy = t.cpad;
-            if (t.cpad != l.Cout) SSD_HIP(hipMemsetAsync(s.scratch_dy, 0, (size_t)M * ldy * sizeof(float), st));
+            if (t.cpad != l.Cout) SSD_HIP(hipMemsetAsync(dyb, 0, (size_t)M * ldy * sizeof(float), st));
             hipLaunchKernelGGL(gather_head_kernel, dim3(grid_for(M * l.Cout1)), dim3(256), 0, st, s.glogits, l.head_bs,
-                               l.head_off, l.head_ps, B, l.Ho * l.Wo, l.Cout1, s.scratch_dy, ldy, 0);
+                               l.head_off, l.head_ps, B, l.Ho * l.Wo, l.Cout1, dyb, ldy, 0);
             hipLaunchKernelGGL(gather_head_kernel, dim3(grid_for(M * (l.Cout - l.Cout1))), dim3(256), 0, st, s.gdeltas,
-                               l.head2_bs, l.head2_off, l.head2_ps, B, l.Ho * l.Wo, l.Cout - l.Cout1, s.scratch_dy, ldy,
+                               l.head2_bs, l.head2_off, l.head2_ps, B, l.Ho * l.Wo, l.Cout - l.Cout1, dyb, ldy,
                                l.Cout1);
             SSD_LAUNCH_CHECK();
-            dY = s.scratch_dy;
+            dY = dyb;
             // bias gradients = column sums
             RedParams rp{};
             rp.a = dY; rp.M = M; rp.C = l.Cout; rp.lda = ldy;
@@ -1602,9 +1659,9 @@ int ssd_net_train_forward_backward(ssd_net* net, const float* image_dev, int B, 
                 if (rc) return rc;
                 hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid_for(M * l.Cout)), dim3(256), 0, st, dOut, t.pre, M, l.Cout,
                                    t.mean, t.istd, net->params[l.p_bn].dev, net->params[l.p_bn + 1].dev, l.act,
-                                   grads_flat_dev + t.g_gamma, grads_flat_dev + t.g_beta, s.scratch_dy);
+                                   grads_flat_dev + t.g_gamma, grads_flat_dev + t.g_beta, dyb);
                 SSD_LAUNCH_CHECK();
-                dY = s.scratch_dy;
+                dY = dyb;
             } else {
                 RedParams rp{};
                 rp.a = dOut; rp.b = l.act ? s.act[l.out] : nullptr;
@@ -1615,9 +1672,9 @@ int ssd_net_train_forward_backward(ssd_net* net, const float* image_dev, int B, 
                 if (rc) return rc;
                 if (l.act) {
                     hipLaunchKernelGGL(act_bwd_kernel, dim3(grid_for(M * l.Cout)), dim3(256), 0, st, dOut, s.act[l.out],
-                                       M * l.Cout, l.act, s.scratch_dy);
+                                       M * l.Cout, l.act, dyb);
                     SSD_LAUNCH_CHECK();
-                    dY = s.scratch_dy;
+                    dY = dyb;
                 } else {
                     dY = dOut;
                 }
@@ -1648,12 +1705,21 @@ int ssd_net_train_forward_backward(ssd_net* net, const float* image_dev, int B, 
             s.gwritten[l.in] = 1;
             continue;
         }
-        // ---- dense conv: weight gradient(s)
+        // ---- dense conv: weight gradient(s), on the side stream behind dY (they are needed only at the end of the step /
+        // at their gradient bucket: the data-gradient chain below does not wait for them)
+        // (not under the bucketed data-parallel exchange: there the communication stream already runs beside the backward,
+        // and a third stream measured slower at world size 1 -- 12.6 against 11.5 ms -- than the weight gradients in line)
+        const bool side = s.wstream && s.bucket_lo.empty();
+        hipStream_t wst = side ? s.wstream : st;
+        if (side) {
+            SSD_HIP(hipEventRecord(s.ev_dy, st));
+            SSD_HIP(hipStreamWaitEvent(s.wstream, s.ev_dy, 0));
+        }
         if (l.p_kernel2 < 0) {
-            rc = wgrad(s, l, B, x, dY, ldy, l.Cout, grads_flat_dev + t.g_kernel, st);
+            rc = wgrad(s, l, B, x, dY, ldy, l.Cout, grads_flat_dev + t.g_kernel, wst);
         } else {
-            rc = wgrad(s, l, B, x, dY, ldy, l.Cout1, grads_flat_dev + t.g_kernel, st);
-            if (!rc) rc = wgrad(s, l, B, x, dY + l.Cout1, ldy, l.Cout - l.Cout1, grads_flat_dev + t.g_kernel2, st);
+            rc = wgrad(s, l, B, x, dY, ldy, l.Cout1, grads_flat_dev + t.g_kernel, wst);
+            if (!rc) rc = wgrad(s, l, B, x, dY + l.Cout1, ldy, l.Cout - l.Cout1, grads_flat_dev + t.g_kernel2, wst);
         }
         if (rc) return rc;
         // VGG16: kernel_regularizer=l2(5e-4) on every backbone / extra conv (models/ssd_vgg16.py:44-45; the head
@@ -1661,9 +1727,13 @@ int ssd_net_train_forward_backward(ssd_net* net, const float* image_dev, int B, 
         // weight gradient so that the gradient bucket it lies in is final when the backward has passed the layer
         if (net->backbone == SSD_VGG16 && !l.head_kind) {
             const Param& w = net->params[l.p_kernel];
-            hipLaunchKernelGGL(axpy_kernel, dim3(grid_for((long)w.count)), dim3(256), 0, st, grads_flat_dev + t.g_kernel,
+            hipLaunchKernelGGL(axpy_kernel, dim3(grid_for((long)w.count)), dim3(256), 0, wst, grads_flat_dev + t.g_kernel,
                                w.dev, (long)w.count, 2.0f * 5e-4f);
             SSD_LAUNCH_CHECK();
+        }
+        if (side && dY == dyb) {             // the buffer may be rewritten only after this weight gradient
+            SSD_HIP(hipEventRecord(s.ev_wdone[dy_cur], s.wstream));
+            s.wpending[dy_cur] = true;
         }
         // ---- data gradient: conv of dY with the rotated / transposed weights
         if (!t.wbwd) continue;
@@ -1693,6 +1763,8 @@ int ssd_net_train_forward_backward(ssd_net* net, const float* image_dev, int B, 
         if (rc) return rc;
         s.gwritten[l.in] = 1;
     }
+    rc = join_wgrads();             // the caller's stream sees the complete gradient vector
+    if (rc) return rc;
     rc = mark_ready(0);
     if (rc) return rc;
     return SSD_OK;
