@@ -734,6 +734,42 @@ def test_image_block_kernel_vs_layer_kernels(B, ticket):
         np.testing.assert_array_equal(m.fetch_activation(n), got[n])
 
 
+@pytest.mark.parametrize("B", [3, 64])
+def test_image_block_split_form_vs_layer_kernels(B):
+    """The whole-image kernel's split-bf16 form (img_choice 2: both 1x1 convolutions as exact three-way bf16 splits,
+    six v_mfma_f32_16x16x32_bf16 per product, fp32 results; weights staged through LDS) pinned on every block it can
+    run -- the finalize-time race only keeps it where it wins -- against the layer kernels, to the fp32 kernels' own
+    tolerance; the table line reads back as "image 2" and the layer reports "image_split"."""
+    from models.ssd_mobilenet_v2 import get_model
+    hp = helpers.hyper_params("mobilenet_v2")
+    w = helpers.synthetic_weights("mobilenet_v2", hp)
+    x = helpers.images(min(B, 8), 300, seed=19)
+    if B > 8:
+        x = np.concatenate([x] * ((B + 7) // 8))[:B] * np.linspace(0.5, 1.0, B, dtype=np.float32)[:, None, None, None]
+    m = get_model(hp, max_batch=B)
+    m.set_weights(w)
+    names = ["block_%d_out" % k for k in range(7, 17)] + ["block_13_expand_relu"]
+    m.set_option("fuse_image", 0)
+    d0, p0 = m(x)
+    ref = {n: m.fetch_activation(n).copy() for n in names}
+    table = m.get_tuning()
+    pinned = "\n".join((l.rsplit(" ", 1)[0] + " 2") if " image " in l else l for l in table.splitlines()) + "\n"
+    assert pinned.count(" image 2") == 10
+    m.set_tuning(pinned)
+    m.set_option("fuse_image", 1)
+    d1, p1 = m(x)
+    assert m.get_tuning().count(" image 2") == 10
+    cfg = {l["name"]: l["config"] for l in m.layers(B) if l["flops"] > 0}
+    assert all(cfg.get("block_%d_fused" % k) == "image_split" for k in range(7, 17)), cfg
+    for n in names:
+        scale = np.abs(ref[n]).max()
+        assert np.abs(m.fetch_activation(n) - ref[n]).max() <= 2e-5 * scale, n
+    assert np.abs(_np(p1) - _np(p0)).max() <= 2e-5
+    d2, p2 = m(x)
+    np.testing.assert_array_equal(_np(d2), _np(d1))
+    np.testing.assert_array_equal(_np(p2), _np(p1))
+
+
 def test_get_head_from_outputs_composition():
     """models.header.get_head_from_outputs (reference models/header.py:43-67) as a composition of
     op-level C-ABI calls vs the NumPy oracle: 12 head convs stored at their level offsets of the

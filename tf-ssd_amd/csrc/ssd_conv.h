@@ -109,6 +109,7 @@ int launch_band3_block(FusedBlockParams p, hipStream_t st);
 bool band_block_supported(const FusedBlockParams& p);
 int launch_band_block(FusedBlockParams p, hipStream_t st);
 bool image_block_supported(const FusedBlockParams& p);
+bool image_block_split_fits(FusedBlockParams p);     // the split-bf16 form's LDS tiles fit at p.groups
 int image_block_groups(const FusedBlockParams& p, int B);
 size_t image_block_slab_floats(const FusedBlockParams& p, int B);
 int launch_image_block(FusedBlockParams p, hipStream_t st);

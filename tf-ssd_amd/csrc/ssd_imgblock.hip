@@ -392,24 +392,35 @@ __global__ __launch_bounds__(kIThreads) void mbv2_image_block_kernel(const Fused
     }
     ITICK(5);
     IDUMP();
-#undef ITICK
-#undef IDUMP
 }
 
 
 // ---------------------------------------------------------------------------------------------------------------
 // The same block on the BF16 matrix cores (the net's precision-1 "bf16" mode: NP = 1, every operand of the two 1x1
-// convolutions rounded once to bf16, ONE v_mfma_f32_16x16x32_bf16 per product, fp32 accumulation; NP = 3 -- the exact
-// three-way split, fp32 results -- compiles from the same source for experiments).  Differences to the kernel above:
+// convolutions rounded once to bf16, ONE v_mfma_f32_16x16x32_bf16 per product, fp32 accumulation) and, NP = 3, its
+// split-bf16 form for the fp32 net: the exact three-way split of both operands, six matrix instructions per product, fp32
+// results (FusedBlockParams.bf16 == 3; it enters the finalize-time race as img_choice 2 and wins blocks 7-10 and 13-15 at
+// B = 64: 42-65 -> 35-53 us; the 96-channel blocks 11-12 spill 91 registers in this form and stay on the kernel above).
+// Differences to the kernel above:
 //   * X is converted once into bf16 B fragments (lane = pixel x 8 channels per 32-wide k-step): CIN / 8 registers per
 //     pixel tile instead of CIN / 4
-//   * no weight staging in LDS: the A fragments of the expand (bf16 plane of the scale-folded We, [Ce][kpad_e]) and of the
-//     project ([npad_p][kpad_p]) are read straight from L1 / L2, one chunk ahead of their use
+//   * the A fragments come from the bf16 planes of the scale-folded We ([Ce][kpad_e]) / Wp ([npad_p][kpad_p]) through LDS
 //   * the project runs every SECOND 16-channel chunk on K = 32 = the two chunks' depthwise outputs (k-slot (g4, j):
 //     j < 4 -> even chunk channel g4*4 + j, j >= 4 -> odd chunk), converted in registers
 //   * E, the depthwise taps, the BatchNorm shifts, ReLU6, the residual add and the partial-sum slabs stay fp32
+//   * weights through LDS: the chunk's expand rows (Wes, two stages, row stride KS*64 + 32 B) and the chunk pair's project
+//     rows (Wps, one stage, 64-byte rows with the 16-byte slot XOR-swizzled by (row >> 2) & 3) are copied global ->
+//     registers -> LDS one iteration ahead of their use, so no matrix instruction waits on an L2 round trip and a
+//     fragment is one ds_read_b128 (reading them straight from L2, the first form of this kernel, measured 72.0 k against
+//     82.0 k images/s in the bf16 mode and spilled 44-730 registers in the NP = 3 form)
 typedef short bf16x4 __attribute__((ext_vector_type(4)));
-
+#ifdef SSD_IMAGE16_PROF
+#define I16TICK(i) ITICK(i)
+#define I16DUMP() IDUMP()
+#else
+#define I16TICK(i) do {} while (0)
+#define I16DUMP() do {} while (0)
+#endif
 template <int CIN, int NT, int T, int S, int NP>
 __global__ __launch_bounds__(kIThreads) void mbv2_image16_block_kernel(const FusedBlockParams p) {
     static_assert(CIN % 32 == 0, "whole 32-channel k-steps");
@@ -417,6 +428,9 @@ __global__ __launch_bounds__(kIThreads) void mbv2_image16_block_kernel(const Fus
     constexpr int KS = CIN / 32;                  // k-steps of the expand
     constexpr int TO = S == 1 ? T : 1;            // output pixel tiles per wave
     constexpr int NCH = T == 1 ? 2 : 1;           // independent expand accumulator chains per tile
+    constexpr int SEH = KS * 32 + 16;             // Wes row stride in bf16 (KS*4 + 2 quads: 2 mod 4)
+    constexpr int WE_U = NP * 16 * KS * 4, WE_R = (WE_U + kIThreads - 1) / kIThreads;       // 16-byte units of a We chunk
+    constexpr int WP_U = NP * NT * 16 * 8, WP_R = (WP_U + kIThreads - 1) / kIThreads;       // 8-byte units of a Wp chunk pair
 
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, g4 = lane >> 4;
@@ -427,11 +441,60 @@ __global__ __launch_bounds__(kIThreads) void mbv2_image16_block_kernel(const Fus
     const int NE = npt * 16 + 2 * P + 2;          // E rows: index q + P + 1, zero rows above / below
     const int CeG = p.Ce / G, cbeg = grp * CeG, nchunk = CeG / kIC;
 
+#ifdef SSD_IMAGE16_PROF                          // diagnostics build only (phases as in the kernel above): the counters cost registers
+    long long tacc[6] = {0, 0, 0, 0, 0, 0};
+    long long t0 = p.dbg ? clock64() : 0;
+#endif
     float* Es = sm;                               // [2][NE][kILD]
     float* Ps = Es + 2 * NE * kILD;               // [11][CeG]: expand shift, depthwise taps [9], depthwise shift
+    short* Wes = reinterpret_cast<short*>(Ps + 11 * CeG);      // [2][NP][16][SEH]
+    short* Wps = Wes + 2 * NP * 16 * SEH;                      // [NP][NT*16][32]
     const long plane_e = (long)p.Ce * p.kpad_e, plane_p = (long)p.npad_p * p.kpad_p;
     const short* we16 = p.we3 + WPL * plane_e;
     const short* wp16 = p.wp3 + WPL * plane_p;
+
+    // ---- weight chunks global -> registers -> LDS
+    constexpr int WE_N = WE_R, WP_N = WP_R;
+    bf16x8 wer[WE_N];
+    bf16x4 wpr[WP_N];
+    auto stage_we_load_to = [&](bf16x8 (&wer)[WE_N], int j) {
+#pragma unroll
+        for (int i = 0; i < WE_R; ++i) {
+            const int u = min(tid + i * kIThreads, WE_U - 1);
+            const int quad = u % (KS * 4), row = (u / (KS * 4)) & 15, pl = u / (KS * 64);
+            wer[i] = *reinterpret_cast<const bf16x8*>(we16 + pl * plane_e + (long)(cbeg + j * kIC + row) * p.kpad_e + quad * 8);
+        }
+    };
+    auto stage_we_store_from = [&](const bf16x8 (&wer)[WE_N], int buf) {
+#pragma unroll
+        for (int i = 0; i < WE_R; ++i) {
+            const int u = tid + i * kIThreads;
+            const int quad = u % (KS * 4), row = (u / (KS * 4)) & 15, pl = u / (KS * 64);
+            if (u < WE_U) *reinterpret_cast<bf16x8*>(Wes + ((buf * NP + pl) * 16 + row) * SEH + quad * 8) = wer[i];
+        }
+    };
+    auto stage_we_load = [&](int j) { stage_we_load_to(wer, j); };
+    auto stage_we_store = [&](int buf) { stage_we_store_from(wer, buf); };
+    // pair = chunks (2 pair, 2 pair + 1); the half of a lone last chunk's partner is zero
+    auto stage_wp_load = [&](int pair) {
+#pragma unroll
+        for (int i = 0; i < WP_R; ++i) {
+            const int u = min(tid + i * kIThreads, WP_U - 1);
+            const int q4 = u & 3, half = (u >> 2) & 1, row = (u >> 3) % (NT * 16), pl = u / (NT * 128);
+            const int ch = 2 * pair + half;
+            wpr[i] = ch < nchunk ? *reinterpret_cast<const bf16x4*>(wp16 + pl * plane_p + (long)row * p.kpad_p + cbeg + ch * kIC + q4 * 4)
+                                 : bf16x4{0, 0, 0, 0};
+        }
+    };
+    auto stage_wp_store = [&]() {
+#pragma unroll
+        for (int i = 0; i < WP_R; ++i) {
+            const int u = tid + i * kIThreads;
+            const int q4 = u & 3, half = (u >> 2) & 1, row = (u >> 3) % (NT * 16), pl = u / (NT * 128);
+            if (u < WP_U)
+                *reinterpret_cast<bf16x4*>(Wps + (pl * NT * 16 + row) * 32 + ((q4 ^ ((row >> 2) & 3)) * 8) + half * 4) = wpr[i];
+        }
+    };
 
     for (int u = tid; u < 2 * (2 * P + 2) * (kILD / 4); u += kIThreads) {
         const int buf = u / ((2 * P + 2) * (kILD / 4)), v = u - buf * ((2 * P + 2) * (kILD / 4));
@@ -483,16 +546,17 @@ __global__ __launch_bounds__(kIThreads) void mbv2_image16_block_kernel(const Fus
         const float* src = row == 0 ? p.eh : row == 10 ? p.dh : p.wd + (long)(row - 1) * p.Ce;
         *reinterpret_cast<f32x4*>(Ps + row * CeG + c4) = *reinterpret_cast<const f32x4*>(src + cbeg + c4);
     }
-    // expand A fragments of chunk j: row = the chunk's channel l15, k = ks*32 + g4*8 .. +7
-    auto load_we = [&](BP<NP> (&w)[KS], int j) {
-        const short* wr = we16 + (long)(cbeg + j * kIC + l15) * p.kpad_e + g4 * 8;
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks)
-#pragma unroll
-            for (int pl = 0; pl < NP; ++pl) w[ks].p[pl] = *reinterpret_cast<const bf16x8*>(wr + pl * plane_e + ks * 32);
-    };
-    BP<NP> wea[KS];
-    load_we(wea, 0);
+    {               // start-up: We(0), We(1), Wp(pair 0) in flight together, then We(2) and Wp(pair 1) into the loop's registers
+        bf16x8 w0[WE_N], w1[WE_N];
+        stage_we_load_to(w0, 0);
+        stage_we_load_to(w1, nchunk > 1 ? 1 : 0);
+        stage_wp_load(0);
+        stage_we_store_from(w0, 0);
+        stage_we_store_from(w1, 1);
+        stage_wp_store();
+        if (nchunk > 2) stage_we_load(2);
+        if (nchunk > 2) stage_wp_load(1);
+    }
     __syncthreads();
 
     auto expand = [&](int j) {
@@ -503,10 +567,15 @@ __global__ __launch_bounds__(kIThreads) void mbv2_image16_block_kernel(const Fus
             ea[t][0] = sh;
             if (NCH == 2) ea[t][NCH - 1] = f32x4{0.f, 0.f, 0.f, 0.f};
         }
+        const short* wl = Wes + ((j & 1) * NP * 16 + l15) * SEH + g4 * 8;
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks)
+        for (int ks = 0; ks < KS; ++ks) {
+            BP<NP> wea;
 #pragma unroll
-            for (int t = 0; t < T; ++t) ea[t][ks % NCH] = mmaN<NP>(wea[ks], xs[t][ks], ea[t][ks % NCH]);
+            for (int pl = 0; pl < NP; ++pl) wea.p[pl] = *reinterpret_cast<const bf16x8*>(wl + pl * 16 * SEH + ks * 32);
+#pragma unroll
+            for (int t = 0; t < T; ++t) ea[t][ks % NCH] = mmaN<NP>(wea, xs[t][ks], ea[t][ks % NCH]);
+        }
         float* es = Es + ((j & 1) * NE + P + 1) * kILD + g4 * 4;
 #pragma unroll
         for (int t = 0; t < T; ++t) {
@@ -527,27 +596,28 @@ __global__ __launch_bounds__(kIThreads) void mbv2_image16_block_kernel(const Fus
 #pragma unroll
         for (int ni = 0; ni < NT; ++ni) acc[t][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+    I16TICK(0);
     expand(0);
-    if (nchunk > 1) load_we(wea, 1);
     f32x4 dprev[TO];
+    I16TICK(4);
 
     for (int i = 0; i < nchunk; ++i) {
         lds_barrier();          // E(i) is visible; everyone is done with E(i - 1)
+        I16TICK(1);
         const bool odd = i & 1;
         const bool flush = odd || i + 1 == nchunk;
-        // project A fragments of the chunk pair (i - 1, i) / the lone last chunk: in flight across the depthwise
-        bf16x4 wlo[NT][NP], whi[NT][NP];
-        if (flush) {
-            const short* wr = wp16 + (long)l15 * p.kpad_p + cbeg + (i & ~1) * kIC + g4 * 4;
-#pragma unroll
-            for (int ni = 0; ni < NT; ++ni)
-#pragma unroll
-                for (int pl = 0; pl < NP; ++pl) {
-                    const short* r = wr + (long)ni * 16 * p.kpad_p + pl * plane_p;
-                    wlo[ni][pl] = *reinterpret_cast<const bf16x4*>(r);
-                    whi[ni][pl] = odd ? *reinterpret_cast<const bf16x4*>(r + kIC) : bf16x4{0, 0, 0, 0};
-                }
+        {
+            // We(i + 2) (loaded an iteration ago) -> the stage expand(i) read before this barrier; We(i + 3) on its way
+            if (i + 2 < nchunk) stage_we_store(i & 1);
+            if (i + 3 < nchunk) stage_we_load(i + 3);
+            // Wp of the pair (i, i + 1): everyone projected the pair before at iteration i - 1; then the next pair's
+            // loads go out, two iterations ahead of their store
+            if (!odd && i > 0 && i + 1 < nchunk) {
+                stage_wp_store();
+                if (i + 2 < nchunk) stage_wp_load((i >> 1) + 1);
+            }
         }
+        I16TICK(4);
         // ---- depthwise in MFMA-fragment layout
         f32x4 a[TO];
         {
@@ -571,6 +641,7 @@ __global__ __launch_bounds__(kIThreads) void mbv2_image16_block_kernel(const Fus
 #pragma unroll
                 for (int e = 0; e < 4; ++e) a[t][e] = __builtin_amdgcn_fmed3f(a[t][e], 0.0f, 6.0f);
         }
+        I16TICK(2);
         // ---- project (every second chunk: K = 32)
         if (!flush) {
 #pragma unroll
@@ -583,15 +654,23 @@ __global__ __launch_bounds__(kIThreads) void mbv2_image16_block_kernel(const Fus
             for (int ni = 0; ni < NT; ++ni) {
                 BP<NP> wa;
 #pragma unroll
-                for (int pl = 0; pl < NP; ++pl) wa.p[pl] = __builtin_shufflevector(wlo[ni][pl], whi[ni][pl], 0, 1, 2, 3, 4, 5, 6, 7);
+                for (int pl = 0; pl < NP; ++pl) {
+                    const int row = ni * 16 + l15;
+                    wa.p[pl] = *reinterpret_cast<const bf16x8*>(Wps + (pl * NT * 16 + row) * 32 + ((g4 ^ ((row >> 2) & 3)) * 8));
+                }
 #pragma unroll
                 for (int t = 0; t < TO; ++t) acc[t][ni] = mmaN<NP>(wa, d[t], acc[t][ni]);
             }
         }
+        I16TICK(3);
+        if (odd && i + 2 == nchunk) {     // the next chunk is a lone last one: its project reads Wps in its own iteration
+            lds_barrier();
+            stage_wp_store();
+        }
         if (i + 1 < nchunk) {
             expand(i + 1);
-            if (i + 2 < nchunk) load_we(wea, i + 2);        // in flight across the barrier and the next depthwise
         }
+        I16TICK(4);
     }
 
     // ---- epilogue (fp32): G = 1 direct; G > 1 partial-sum slab, combined by image_combine_kernel
@@ -609,6 +688,8 @@ __global__ __launch_bounds__(kIThreads) void mbv2_image16_block_kernel(const Fus
                 *reinterpret_cast<f32x4*>(yp + ni * 16) = v;
             }
         }
+        I16TICK(5);
+        I16DUMP();
         return;
     }
     const long slab_stride = (long)B * Ho * Wo * p.Cout;
@@ -619,7 +700,13 @@ __global__ __launch_bounds__(kIThreads) void mbv2_image16_block_kernel(const Fus
 #pragma unroll
         for (int ni = 0; ni < NT; ++ni) *reinterpret_cast<f32x4*>(sp + (long)opo[t] * p.Cout + ni * 16) = acc[t][ni];
     }
+    I16TICK(5);
+    I16DUMP();
 }
+#undef ITICK
+#undef IDUMP
+#undef I16TICK
+#undef I16DUMP
 
 // y = shift + sum of the G slabs in group order (+ residual): the combine as its own launch
 __global__ __launch_bounds__(256) void image_combine_kernel(const float* __restrict__ slabs, const float* __restrict__ ph,
@@ -646,9 +733,12 @@ struct ImageCfg {
     int cin, nt, t, stride;
     image_kernel_t fn;
     image_kernel_t fn16;        // the bf16 form (precision 1)
+    image_kernel_t fn3;         // the split-bf16 form: fp32 results on the bf16 matrix cores (FusedBlockParams.bf16 == 3)
 };
-#define ICFG(CIN, NT, T) {CIN, NT, T, 1, mbv2_image_block_kernel<CIN, NT, T, 1>, mbv2_image16_block_kernel<CIN, NT, T, 1, 1>}
-#define ICFG2(CIN, NT, T) {CIN, NT, T, 2, mbv2_image_block_kernel<CIN, NT, T, 2>, mbv2_image16_block_kernel<CIN, NT, T, 2, 1>}
+#define ICFG(CIN, NT, T) {CIN, NT, T, 1, mbv2_image_block_kernel<CIN, NT, T, 1>, mbv2_image16_block_kernel<CIN, NT, T, 1, 1>, \
+                             mbv2_image16_block_kernel<CIN, NT, T, 1, 3>}
+#define ICFG2(CIN, NT, T) {CIN, NT, T, 2, mbv2_image_block_kernel<CIN, NT, T, 2>, mbv2_image16_block_kernel<CIN, NT, T, 2, 1>, \
+                              mbv2_image16_block_kernel<CIN, NT, T, 2, 3>}
 const ImageCfg kImage[] = {
     ICFG(64, 4, 3),     // blocks 7-9:   64 -> 384 -> 64 at 19x19
     ICFG(64, 6, 3),     // block 10:     64 -> 384 -> 96
@@ -660,7 +750,11 @@ const ImageCfg kImage[] = {
 
 size_t image_lds_bytes(const ImageCfg& c, const FusedBlockParams& p, int G) {
     const int P = p.W + 1, npt = (p.H * P + 15) / 16, NE = npt * 16 + 2 * P + 2;
-    if (p.bf16) return ((size_t)2 * NE * kILD + (size_t)11 * (p.Ce / G) + 4) * sizeof(float);      // no weight tiles in LDS
+    if (p.bf16) {
+        const int np = p.bf16 == 3 ? 3 : 1, ks = c.cin / 32;
+        const size_t w = (size_t)(2 * np * 16 * (ks * 32 + 16) + np * c.nt * 16 * 32) * sizeof(short);      // Wes + Wps
+        return ((size_t)2 * NE * kILD + (size_t)11 * (p.Ce / G) + 4) * sizeof(float) + w;
+    }
     const size_t fl = (size_t)2 * NE * kILD + (size_t)2 * kIC * (c.cin + 8) + (size_t)2 * c.nt * 16 * kILD +
                       (size_t)11 * (p.Ce / G) + 4;
     return fl * sizeof(float);
@@ -675,9 +769,11 @@ const ImageCfg* pick_image(const FusedBlockParams& p) {
     if (p.stride != 1 && p.stride != 2) return nullptr;
     if (p.residual && p.Cin != p.Cout) return nullptr;
     const int npt = (p.H * (p.W + 1) + 15) / 16;
+    FusedBlockParams q = p;
+    if (q.bf16 == 3) q.bf16 = 0;        // the split form falls back to the fp32 form where its weight tiles do not fit
     for (const auto& c : kImage)
         if (c.cin == p.Cin && c.nt * 16 == p.Cout && c.stride == p.stride && npt <= 8 * c.t && npt > 8 * (c.t == 3 ? 1 : 0) &&
-            image_lds_bytes(c, p, 1) <= 160 * 1024)
+            image_lds_bytes(c, q, 1) <= 160 * 1024)
             return &c;
     return nullptr;
 }
@@ -685,6 +781,11 @@ const ImageCfg* pick_image(const FusedBlockParams& p) {
 }  // namespace
 
 bool image_block_supported(const FusedBlockParams& p) { return pick_image(p) != nullptr; }
+bool image_block_split_fits(FusedBlockParams p) {
+    const ImageCfg* c = pick_image(p);
+    p.bf16 = 3;
+    return c && p.we3 && p.wp3 && image_lds_bytes(*c, p, p.groups < 1 ? 1 : p.groups) <= 160 * 1024;
+}
 
 // Number of expanded-channel groups for batch B: the smallest divisor of Ce / 16 that fills the
 // CUs (one workgroup per CU: 78-120 KB of LDS), at most 12.
@@ -724,11 +825,12 @@ int launch_image_block(FusedBlockParams p, hipStream_t st) {
     if (!p.ablate) p.ablate = ablate;
     SSD_CHECK_ARG((p.Ce / kIC) % p.groups == 0, "image block: %d groups do not divide Ce/16 = %d", p.groups, p.Ce / kIC);
     SSD_CHECK_ARG(p.groups == 1 || p.slabs, "image block: %d groups need the slab workspace", p.groups);
+    if (p.bf16 == 3 && image_lds_bytes(*c, p, p.groups) > 160 * 1024) p.bf16 = 0;      // split form's weight tiles do not fit: fp32 form
     const size_t lds = image_lds_bytes(*c, p, p.groups);
     SSD_UNSUPPORTED_IF(lds > 160 * 1024, "image block: needs %zu B of LDS", lds);
     SSD_CHECK_ARG(!p.bf16 || (p.we3 && p.wp3), "image block: the bf16 form needs the weights' bf16 planes");
     SSD_CHECK_ARG(!p.bf16 || !p.tickets, "image block: the bf16 form combines by the second launch only");
-    const image_kernel_t fn = p.bf16 ? c->fn16 : c->fn;
+    const image_kernel_t fn = p.bf16 == 3 ? c->fn3 : p.bf16 ? c->fn16 : c->fn;
     if (lds > 64 * 1024)
         SSD_HIP(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     // groups > 1: p.tickets == nullptr (default) combines the group slabs in a second launch -- the

@@ -59,7 +59,7 @@ struct Layer {
                                     // 2: depthwise + project (the expand conv stays a GEMM of its own)
     int fused_by = -1;
  int e_out = -1;                 // whole-block LK_FUSED layer that must ALSO materialise its expanded map: that tensor
-    int img_choice = -1;            // whole-block LK_FUSED layers the image kernel can run: 1 = it won the finalize-time race against the layer kernels, 0 = it lost, -1 = not timed
+    int img_choice = -1;            // whole-block LK_FUSED layers the image kernel can run: 1 / 2 = its fp32-MFMA / split-bf16 form won the finalize-time race against the layer kernels, 0 = it lost, -1 = not timed
     int fused_by2 = -1;             // depthwise / project members: their type-2 LK_FUSED layer
     float* splitk_part = nullptr;   // this layer's own split-K slab (layers may run concurrently)
     // LK_FUSED: weight copies with the folded BatchNorm scale multiplied in (per output channel)
@@ -93,6 +93,7 @@ struct ssd_net {
     int lanes_hint = 1;             // replicas of this net running concurrently (lanes): the whole-image kernel then splits an image's expanded channels over fewer workgroups (B x groups x lanes fills the CUs; fewer slab passes)
     int tail_prio = 0;              // 1: extras tail on side[2] (highest priority); 2: its small heads too
     bool tail_on_side = false;      // diagnostics: big heads on the main stream, extras tail + small heads on the side streams
+    bool image_split = true;        // fp32 nets: the finalize-time race also times the image kernel's split-bf16 form (img_choice 2; SSD_IMAGE_SPLIT=0 / option "image_split" 0: leave it out)
     bool image_ticket = false;      // combine the channel-group slabs inside the launch (arrival ticket) instead of by a second launch
     float* img_slabs = nullptr;     // its partial-sum slabs and arrival tickets (sized for max_batch)
     unsigned* img_tickets = nullptr;

@@ -365,6 +365,7 @@ static FusedBlockParams fused_params(const ssd_net& net, const Layer& f, int B) 
         p.groups = net.img_slabs ? image_block_groups(p, B * net.lanes_hint) : 1;
         p.slabs = net.img_slabs;
         p.tickets = net.image_ticket ? net.img_tickets : nullptr;
+        if (!p.bf16 && f.img_choice == 2) { p.bf16 = 3; p.tickets = nullptr; }    // the split-bf16 form of the image kernel (fp32 results)
     }
     return p;
 }
@@ -464,7 +465,7 @@ static bool fused_active(const ssd_net& net, const Layer& f) {
     }
     const FusedBlockParams p = fused_params(net, f, 1);
     if (fused_block_supported(p)) return true;
-    if (!net.fuse_image || (net.fuse_image == 1 && f.img_choice != 1)) return false;
+    if (!net.fuse_image || (net.fuse_image == 1 && f.img_choice < 1)) return false;
     return image_block_supported(p);
 }
 static bool layer_runs(const ssd_net& net, const Layer& l) {
@@ -514,9 +515,11 @@ static int tune_image_blocks(ssd_net& net, int B, hipStream_t st) {
         const FusedBlockParams p = fused_params(net, f, B);
         if (fused_block_supported(p) || !image_block_supported(p)) { f.img_choice = 0; continue; }
         if (f.img_choice >= 0) continue;        // preset line
-        float ms[2] = {1e30f, 1e30f};
-        for (int choice = 0; choice < 2 && !rc; ++choice) {
+        float ms[3] = {1e30f, 1e30f, 1e30f};
+        const int nchoice = net.precision == 0 && net.image_split ? 3 : 2;     // 2: the fp32 net's split-bf16 form
+        for (int choice = 0; choice < nchoice && !rc; ++choice) {
             f.img_choice = choice;
+            if (choice == 2 && !image_block_split_fits(fused_params(net, f, B))) continue;
             for (int trial = 0; trial < 4 && !rc; ++trial) {        // trial 0 warms up
                 (void)hipEventRecord(se0.e, st);
                 for (int r = 0; r < 4 && !rc; ++r)
@@ -530,7 +533,7 @@ static int tune_image_blocks(ssd_net& net, int B, hipStream_t st) {
                 if (trial && t < ms[choice]) ms[choice] = t;
             }
         }
-        f.img_choice = ms[1] < ms[0] ? 1 : 0;
+        f.img_choice = ms[2] < ms[1] && ms[2] < ms[0] ? 2 : ms[1] < ms[0] ? 1 : 0;
     }
     return rc;
 }
@@ -709,6 +712,7 @@ ssd_net* ssd_net_create(int backbone, int img_size, int levels, const int* n_ars
         }
     if (const char* g = getenv("SSD_TAIL_PRIO")) net->tail_prio = atoi(g) < 0 ? 0 : (atoi(g) > 2 ? 2 : atoi(g));    // diagnostics
     if (const char* g = getenv("SSD_FUSE_SOFTMAX")) net->fuse_softmax = atoi(g) != 0;    // diagnostics (A/B of the decoder tail)
+    if (const char* g = getenv("SSD_IMAGE_SPLIT")) net->image_split = atoi(g) != 0;      // diagnostics (A/B of the image kernel's forms)
     if (const char* g = getenv("SSD_HIP_USE_GRAPH")) {      // diagnostics: pin the launch mode (0 direct, 1 graph replay)
         net->use_graph = atoi(g) != 0 && !net->graphs_unsafe;
         net->use_graph_auto = false;
@@ -996,7 +1000,8 @@ int ssd_net_finalize(ssd_net* net, int max_batch) {
         if (fused_block_supported(p) || !image_block_supported(p)) continue;
         auto it = net->preset.find(f.name);
         if (it == net->preset.end() || it->second.first != "image") { image_preset_ok = false; continue; }
-        f.img_choice = it->second.second ? 1 : 0;
+        f.img_choice = it->second.second < 0 ? 0 : it->second.second > 2 ? 2 : it->second.second;
+        if (f.img_choice == 2 && (net->precision != 0 || !net->image_split)) f.img_choice = 1;
     }
     int rc = SSD_OK;
     if (ws_need > net->splitk_floats) {
@@ -1445,6 +1450,12 @@ int ssd_net_set_option(ssd_net* net, const char* name, int value) {
         net->drop_graphs();
         return SSD_OK;
     }
+    if (std::string(name) == "image_split") {    // fp32 nets: let the split-bf16 form of the image kernel into the finalize-time race (default 1)
+        if (net->image_split != (value != 0)) net->finalized = false;
+        net->image_split = value != 0;
+        net->drop_graphs();
+        return SSD_OK;
+    }
     if (std::string(name) == "image_ticket") {
         net->image_ticket = value != 0;
         net->drop_graphs();
@@ -1555,7 +1566,7 @@ const char* ssd_net_layer_config(const ssd_net* net, int i) {
         if (l.f_type == 1) return "stem";
         if (l.f_type == 2) return net->precision ? "dwproj_bf16" : "dwproj";
         const FusedBlockParams p = fused_params(*net, l, 1);
-        if (!fused_block_supported(p)) return net->precision ? "image_bf16" : "image";
+        if (!fused_block_supported(p)) return net->precision ? "image_bf16" : l.img_choice == 2 ? "image_split" : "image";
         if (net->fuse_band == 2 && p.we3 && band3_block_supported(p)) return net->precision ? "band_bf16" : "band3";
         return net->fuse_band && band_block_supported(p) ? "band" : "tile";
     }
