@@ -299,14 +299,16 @@ double ssd_net_layer_executed_flops(const ssd_net* net, int i, int B);
  * GEMM; "fuse_image" (default 1, needs fuse_blocks) lets the whole-image block kernel (blocks
  * 7-12 / 14-16: expand -> depthwise -> project with the expanded map kept on the CU) replace expand
  * GEMM + depthwise/project where it won finalize's on-device race, 2 forces it wherever it applies,
- * 0 disables it; "image_ticket" (default 0) makes that kernel combine its channel-group partial sums
+ * 0 disables it; "image_split" (default 1; fp32 nets) also lets that kernel's split-bf16 form (fp32 results from six bf16
+ * matrix products per product, weights staged through LDS) into the race -- table line "<block> image 2" --, 0 leaves
+ * it out; "image_ticket" (default 0) makes that kernel combine its channel-group partial sums
  * inside the launch (arrival ticket, last arriver) instead of by a second launch; "overlap_heads" (default 1) runs the SSD head convs on side streams ("tail_on_side", default 0,
  * swaps the roles: big head convs on the caller's stream, the small tail layers on the side streams -- measured slower); "use_wino" (default 1)
  * offers the Winograd F(2x2,3x3) kernels to finalize's autotune for the 3x3 stride-1 convs;
  * "precision" (default 0 = fp32, the reference's arithmetic: trainer.py:50-54 has no mixed precision; 1 = bf16, this
  * build's extension for BASELINE.json configs[3] / [4]): every matrix operand of the dense / 1x1 convolutions is rounded
  * once to bf16 (nearest even), each product is one bf16 MFMA with fp32 accumulation ("bf16_*" tiles, the bf16 forms of
- * the row-band and whole-image block kernels); BatchNorm shifts, activations, residual adds, depthwise taps, softmax and
+ * the stem, row-band and whole-image block kernels); BatchNorm shifts, activations, residual adds, depthwise taps, softmax and
  * the box math stay fp32, activations stay fp32 in HBM; the training step then runs its forward / backward-data convs
  * on the bf16 tiles (fp32 master weights, weight gradients and Adam).  Takes effect at the next finalize. */
 int ssd_net_set_option(ssd_net* net, const char* name, int value);

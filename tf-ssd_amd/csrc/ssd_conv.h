@@ -77,6 +77,7 @@ struct StemParams {
     int B, H, W, H1, W1, pad_t, pad_l, kpad1, kpadp;
     int tiles_y, tiles_x;
     int ablate;                 // diagnostics (SSD_STEM_ABLATE): 1 skip Conv1 math, 2 depthwise, 4 project MFMAs, 8 patch loads
+    int bf16;                   // the net's precision: 1 = Conv1 / project operands rounded once to bf16
 };
 // Depthwise 3x3 + BN + ReLU6 -> project 1x1 + BN (+ residual) of one MobileNetV2 block
 // (csrc/ssd_dwproj.hip); BN scales are folded into wd / wp by the caller.
@@ -113,6 +114,7 @@ bool image_block_split_fits(FusedBlockParams p);     // the split-bf16 form's LD
 int image_block_groups(const FusedBlockParams& p, int B);
 size_t image_block_slab_floats(const FusedBlockParams& p, int B);
 int launch_image_block(FusedBlockParams p, hipStream_t st);
+int stem_form(int precision);        // 0 fp32-MFMA, 3 split-bf16 (fp32 results), 1 bf16 operands
 
 inline int round_up(int v, int a) { return (v + a - 1) / a * a; }
 inline int conv_kpad(int K) { return round_up(K, 32); }

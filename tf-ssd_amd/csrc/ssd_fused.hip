@@ -20,6 +20,7 @@
 #include <cstdlib>
 
 #include "ssd_conv.h"
+#include "ssd_bf16x3.h"
 
 namespace ssd {
 
@@ -487,11 +488,15 @@ int launch_fused_block(FusedBlockParams p, hipStream_t st) {
 // pixels: image patch -> LDS, Conv1 on the 10 x 18 halo (VALU, weights broadcast from LDS,
 // zero outside the feature map because the depthwise pads Conv1's OUTPUT), depthwise from LDS
 // (sliding window), project on the fp32 MFMA (K = 32), 16-byte stores.
+// NP selects the matrix instruction of Conv1 and the project: 0 = v_mfma_f32_16x16x4_f32 (exact fp32 products), 3 = the
+// exact three-way bf16 split on v_mfma_f32_16x16x32_bf16 (fp32 results: K = 27 / 32 is ONE k-step, six instructions of
+// 16 cycles instead of eight of 32 per 16 x 16 tile), 1 = operands rounded once to bf16 (the net's bf16 mode).
 constexpr int kSTH = 8, kSTW = 16;
 constexpr int kSIH = kSTH + 2, kSIW = kSTW + 2;           // Conv1 halo tile 10 x 18
 constexpr int kSPH = 2 * (kSIH - 1) + 3, kSPW = 2 * (kSIW - 1) + 3;   // image patch 21 x 37
 constexpr int kSLD = 40;                                  // LDS row stride of the 32-channel tiles (10 quads: conflict-free b128 fragment reads)
 
+template <int NP>
 __global__ __launch_bounds__(256) void mbv2_stem_kernel(const StemParams p) {
     __shared__ __attribute__((aligned(16))) float sm[kSPH * kSPW * 3 + 5 + kSIH * kSIW * kSLD + kSTH * kSTW * kSLD +
                                                        27 * 32 + 9 * 32 + 16 * kSLD + 32 * 2 + 32 * 2 + 16 * 2];
@@ -513,18 +518,41 @@ __global__ __launch_bounds__(256) void mbv2_stem_kernel(const StemParams p) {
     // packed-FMA rate: 63 of the kernel's 131 us), and the patch offsets of ITS four k per k-block
     f32x4 w1a[2][2];
     int koff[2][4];
+    // NP > 0: one 32-wide k-step; lane (ch = l15, g4) holds k = g4*8 .. +7 of both channel tiles as bf16 planes, and the
+    // project's A fragment (row n = l15) the same way
+    BP<NP ? NP : 1> w1b[2], wpb;
+    if (NP == 0) {
 #pragma unroll
-    for (int kb = 0; kb < 2; ++kb)
+        for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-        for (int s4 = 0; s4 < 4; ++s4) {
-            const int k = kb * 16 + (lane >> 4) * 4 + s4;
-            koff[kb][s4] = k < 27 ? (k / 9) * (kSPW * 3) + (k % 9) : 0;      // (ky, kx*3 + ci) inside the patch
+            for (int s4 = 0; s4 < 4; ++s4) {
+                const int k = kb * 16 + (lane >> 4) * 4 + s4;
+                koff[kb][s4] = k < 27 ? (k / 9) * (kSPW * 3) + (k % 9) : 0;      // (ky, kx*3 + ci) inside the patch
+#pragma unroll
+                for (int ct = 0; ct < 2; ++ct) {
+                    const int ch = ct * 16 + (lane & 15);
+                    w1a[ct][kb][s4] = k < 27 ? p.w1[(long)ch * p.kpad1 + k] * p.s1[ch] : 0.f;
+                }
+            }
+    } else {
+        f32x4 wl[2][2];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int k = (lane >> 4) * 8 + j;
+            koff[j >> 2][j & 3] = k < 27 ? (k / 9) * (kSPW * 3) + (k % 9) : 0;
 #pragma unroll
             for (int ct = 0; ct < 2; ++ct) {
                 const int ch = ct * 16 + (lane & 15);
-                w1a[ct][kb][s4] = k < 27 ? p.w1[(long)ch * p.kpad1 + k] * p.s1[ch] : 0.f;
+                wl[ct][j >> 2][j & 3] = k < 27 ? p.w1[(long)ch * p.kpad1 + k] * p.s1[ch] : 0.f;
             }
         }
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct) w1b[ct] = splitN<NP ? NP : 1>(wl[ct][0], wl[ct][1]);
+        const int n = lane & 15;
+        const float* wr = p.wp + (long)n * p.kpadp + (lane >> 4) * 8;
+        f32x4 lo = *reinterpret_cast<const f32x4*>(wr), hi = *reinterpret_cast<const f32x4*>(wr + 4);
+        wpb = splitN<NP ? NP : 1>(lo * p.sp[n], hi * p.sp[n]);
+    }
     for (int e = tid; e < 9 * 32; e += 256) Wd[e] = p.wd[e] * p.sd[e & 31];
     for (int e = tid; e < 16 * 32; e += 256) {
         const int n = e >> 5, k = e & 31;
@@ -547,10 +575,10 @@ __global__ __launch_bounds__(256) void mbv2_stem_kernel(const StemParams p) {
         __syncthreads();        // previous tile fully consumed (and the weights are visible)
         // image patch: 21 rows x 111 contiguous floats
         {
-            constexpr int NP = (kSPH * kSPW * 3 + 255) / 256;
-            float tmp[NP];
+            constexpr int NLD = (kSPH * kSPW * 3 + 255) / 256;
+            float tmp[NLD];
 #pragma unroll
-            for (int i = 0; i < NP; ++i) {                         // all loads in flight together
+            for (int i = 0; i < NLD; ++i) {                         // all loads in flight together
                 const int e = tid + i * 256;
                 const int r = e / (kSPW * 3), j = e - r * (kSPW * 3);
                 const int iy = iy0 + r, ixc = ix0 * 3 + j;         // ixc = ix * 3 + channel
@@ -559,7 +587,7 @@ __global__ __launch_bounds__(256) void mbv2_stem_kernel(const StemParams p) {
                     tmp[i] = img[(long)iy * p.W * 3 + ixc];
             }
 #pragma unroll
-            for (int i = 0; i < NP; ++i) {
+            for (int i = 0; i < NLD; ++i) {
                 const int e = tid + i * 256;
                 if (e < kSPH * kSPW * 3) patch[e] = tmp[i];
             }
@@ -584,19 +612,34 @@ __global__ __launch_bounds__(256) void mbv2_stem_kernel(const StemParams p) {
                 a1[q] = *reinterpret_cast<const f32x4*>(H1 + 16 + (lane >> 4) * 4);
             }
             // six independent accumulator chains (3 pixel tiles x 2 channel tiles) keep the matrix pipe issuing
+            if (NP == 0) {
 #pragma unroll
-            for (int kb = 0; kb < 2; ++kb)
+                for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-                for (int s4 = 0; s4 < 4; ++s4) {
-                    float bq[3];
+                    for (int s4 = 0; s4 < 4; ++s4) {
+                        float bq[3];
 #pragma unroll
-                    for (int q = 0; q < 3; ++q) bq[q] = pp[q][koff[kb][s4]];
+                        for (int q = 0; q < 3; ++q) bq[q] = pp[q][koff[kb][s4]];
 #pragma unroll
-                    for (int q = 0; q < 3; ++q) {
-                        a0[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(w1a[0][kb][s4], bq[q], a0[q], 0, 0, 0);
-                        a1[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(w1a[1][kb][s4], bq[q], a1[q], 0, 0, 0);
+                        for (int q = 0; q < 3; ++q) {
+                            a0[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(w1a[0][kb][s4], bq[q], a0[q], 0, 0, 0);
+                            a1[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(w1a[1][kb][s4], bq[q], a1[q], 0, 0, 0);
+                        }
                     }
+            } else {
+#pragma unroll
+                for (int q = 0; q < 3; ++q) {
+                    f32x4 lo, hi;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        lo[j] = pp[q][koff[0][j]];
+                        hi[j] = pp[q][koff[1][j]];
+                    }
+                    const BP<NP ? NP : 1> b = splitN<NP ? NP : 1>(lo, hi);
+                    a0[q] = mmaN<NP ? NP : 1>(w1b[0], b, a0[q]);
+                    a1[q] = mmaN<NP ? NP : 1>(w1b[1], b, a1[q]);
                 }
+            }
 #pragma unroll
             for (int q = 0; q < 3; ++q) {
                 // ReLU6 inside the feature map, 0 outside (the depthwise pads Conv1's OUTPUT)
@@ -651,16 +694,25 @@ __global__ __launch_bounds__(256) void mbv2_stem_kernel(const StemParams p) {
         const int frow = lane & 15, fk = (lane >> 4) * 4;
         f32x4 acc[2];
         acc[0] = acc[1] = *reinterpret_cast<const f32x4*>(Hp + (lane >> 4) * 4);
+        if (NP == 0) {
 #pragma unroll
-        for (int kc = 0; kc < ((p.ablate & 4) ? 0 : 2); ++kc) {
-            const f32x4 wa = *reinterpret_cast<const f32x4*>(Wp + frow * kSLD + kc * 16 + fk);
-            f32x4 db[2];
+            for (int kc = 0; kc < ((p.ablate & 4) ? 0 : 2); ++kc) {
+                const f32x4 wa = *reinterpret_cast<const f32x4*>(Wp + frow * kSLD + kc * 16 + fk);
+                f32x4 db[2];
 #pragma unroll
-            for (int q = 0; q < 2; ++q) db[q] = *reinterpret_cast<const f32x4*>(D + ((wave + 4 * q) * 16 + frow) * kSLD + kc * 16 + fk);
+                for (int q = 0; q < 2; ++q) db[q] = *reinterpret_cast<const f32x4*>(D + ((wave + 4 * q) * 16 + frow) * kSLD + kc * 16 + fk);
 #pragma unroll
-            for (int s = 0; s < 4; ++s)
+                for (int s = 0; s < 4; ++s)
 #pragma unroll
-                for (int q = 0; q < 2; ++q) acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[s], db[q][s], acc[q], 0, 0, 0);
+                    for (int q = 0; q < 2; ++q) acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[s], db[q][s], acc[q], 0, 0, 0);
+            }
+        } else if (!(p.ablate & 4)) {
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const float* dr = D + ((wave + 4 * q) * 16 + frow) * kSLD + (lane >> 4) * 8;
+                const BP<NP ? NP : 1> b = splitN<NP ? NP : 1>(*reinterpret_cast<const f32x4*>(dr), *reinterpret_cast<const f32x4*>(dr + 4));
+                acc[q] = mmaN<NP ? NP : 1>(wpb, b, acc[q]);
+            }
         }
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
@@ -674,6 +726,13 @@ __global__ __launch_bounds__(256) void mbv2_stem_kernel(const StemParams p) {
 
 bool stem_supported(const StemParams& p) { return p.H1 >= 1 && p.W1 >= 1; }
 
+// Which form of the stem kernel runs for a net of this precision: 1 = bf16 operands (precision 1), 3 = the split-bf16
+// form (fp32 nets; 115 -> 105 us at B = 64), 0 = the fp32-MFMA form (SSD_STEM_FORM=0: diagnostics)
+int stem_form(int precision) {
+    static const int form = getenv("SSD_STEM_FORM") ? atoi(getenv("SSD_STEM_FORM")) : 3;
+    return precision == 1 ? 1 : (form == 3 ? 3 : 0);
+}
+
 int launch_stem(StemParams p, hipStream_t st) {
     if (p.B == 0) return SSD_OK;
     p.tiles_y = (p.H1 + kSTH - 1) / kSTH;
@@ -682,7 +741,9 @@ int launch_stem(StemParams p, hipStream_t st) {
     const long blocks = tiles < 512 ? tiles : 512;           // persistent: 2 workgroups per CU
     static const int ablate = getenv("SSD_STEM_ABLATE") ? atoi(getenv("SSD_STEM_ABLATE")) : 0;
     p.ablate = ablate;
-    hipLaunchKernelGGL(mbv2_stem_kernel, dim3((unsigned)blocks), dim3(256), 0, st, p);
+    const int form = stem_form(p.bf16);
+    const auto fn = form == 1 ? mbv2_stem_kernel<1> : form == 3 ? mbv2_stem_kernel<3> : mbv2_stem_kernel<0>;
+    hipLaunchKernelGGL(fn, dim3((unsigned)blocks), dim3(256), 0, st, p);
     SSD_LAUNCH_CHECK();
     return SSD_OK;
 }

@@ -400,6 +400,7 @@ static StemParams stem_params(const ssd_net& net, const Layer& f, int B) {
     p.B = B; p.H = f.H; p.W = f.W; p.H1 = f.Ho; p.W1 = f.Wo; p.pad_t = f.pt; p.pad_l = f.pl;
     p.kpad1 = conv_kpad(27);
     p.kpadp = conv_kpad(32);
+    p.bf16 = net.precision;
     return p;
 }
 
@@ -1563,7 +1564,7 @@ const char* ssd_net_layer_config(const ssd_net* net, int i) {
     const Layer& l = net->layers[i];
     if (l.kind == LK_FUSED) {        // which fused kernel family runs the block (bench.py prices each at its matrix instruction)
         if (!layer_runs(*net, l)) return "";
-        if (l.f_type == 1) return "stem";
+        if (l.f_type == 1) { const int f = stem_form(net->precision); return f == 1 ? "stem_bf16" : f == 3 ? "stem_split" : "stem"; }
         if (l.f_type == 2) return net->precision ? "dwproj_bf16" : "dwproj";
         const FusedBlockParams p = fused_params(*net, l, 1);
         if (!fused_block_supported(p)) return net->precision ? "image_bf16" : l.img_choice == 2 ? "image_split" : "image";
