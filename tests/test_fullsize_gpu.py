@@ -322,6 +322,51 @@ def test_two_lanes_match_one_lane():
             np.testing.assert_array_equal(a.cpu().numpy(), b)
 
 
+def test_uint8_pinned_batches_are_converted_on_the_lane():
+    """``DecoderModel.submit`` of a PINNED UINT8 batch [B,H,W,3] (the reference's images before ``preprocessing``,
+    utils/data_utils.py:17-22): the lane copies the bytes (a quarter of the float batch over PCIe), runs
+    ``ssd_preprocess`` (x 1/255 + TF2 bilinear resize to the net's input) and the step on its own stream.  Bitwise the
+    detections of the one-at-a-time path on ``data_utils.preprocess_batch`` of the same bytes -- at the net's own size
+    and through a resize (280 x 320 sources) -- for pageable uint8 arrays and the one-lane model as well."""
+    import ssd_hip
+    from models.decoder import get_decoder_model
+    from models.ssd_mobilenet_v2 import get_model
+    from utils import bbox_utils, data_utils
+    hp = helpers.hyper_params("mobilenet_v2")
+    m = get_model(hp, max_batch=4)
+    m.set_weights(helpers.synthetic_weights("mobilenet_v2", hp))
+    priors = bbox_utils.generate_prior_boxes(hp["feature_map_shapes"], hp["aspect_ratios"])
+    dm1 = get_decoder_model(m, priors, hp, lanes=1)
+    dm3 = get_decoder_model(m, priors, hp, lanes=3)
+    rng = np.random.RandomState(5)
+    for (H, W) in ((300, 300), (280, 320)):
+        raw = []
+        for i in range(5):
+            u = (helpers.images(4, 300, seed=60 + i) * 255.0 + 0.5).astype(np.uint8)
+            u = np.pad(u, ((0, 0), (0, 0), (0, max(W - 300, 0)), (0, 0)), mode="edge")[:, :H, :W]
+            raw.append(np.ascontiguousarray(u ^ rng.randint(0, 2, u.shape).astype(np.uint8)))
+        ref = [tuple(t.cpu().numpy() for t in dm1(data_utils.preprocess_batch(r, 300, 300))) for r in raw]
+        assert any((r[2] > 0).sum() > 0 for r in ref)
+        hosts = []
+        for r in raw:
+            hb = ssd_hip.pinned_empty(r.shape, dtype=torch.uint8)
+            hb.numpy()[...] = r
+            hosts.append(hb)
+        outs = [dm3.submit(hb) for hb in hosts]
+        dm3.wait()
+        torch.cuda.synchronize()
+        for o, r in zip(outs, ref):
+            for a, b in zip(o, r):
+                np.testing.assert_array_equal(a.cpu().numpy(), b)
+        for a, b in zip(dm1(raw[0]), ref[0]):                                  # one lane, pageable uint8 array
+            np.testing.assert_array_equal(a.cpu().numpy(), b)
+        o = dm3.submit(raw[1])                                                 # lanes, pageable uint8 array
+        dm3.wait()
+        torch.cuda.synchronize()
+        for a, b in zip(o, ref[1]):
+            np.testing.assert_array_equal(a.cpu().numpy(), b)
+
+
 def test_predict_fused_softmax_matches_the_layered_decoder_across_batch_sizes():
     """``ssd_net_predict`` folds the softmax into the decoder's compaction kernel and keeps its candidate counters zero
     between calls without a memset (csrc/ssd_bbox.hip): bitwise the detections of forward (softmax layer) +

@@ -226,13 +226,22 @@ class DecoderModel(object):
         # queued on the lane's stream in front of its step, so it runs beside the other lanes' kernels and the host
         # never blocks (pageable arrays take the synchronous staged copy of ``to_dev`` on the caller's stream)
         pinned = isinstance(images, torch.Tensor) and images.device.type == "cpu" and images.is_pinned() \
-            and images.dtype == torch.float32 and images.is_contiguous()
+            and images.dtype in (torch.float32, torch.uint8) and images.is_contiguous()
+        # ... and a pinned UINT8 batch [B,H,W,3] (what the reference's dataset holds before ``preprocessing``,
+        # utils/data_utils.py:17-22) crosses PCIe as bytes -- a quarter of the float batch -- and is converted
+        # (x 1/255) + resized to the net's input on the lane's stream by ``ssd_preprocess`` in front of the step
+        u8 = pinned and images.dtype == torch.uint8
+        if u8 and (images.dim() != 4 or images.shape[3] != 3):
+            raise ValueError("uint8 batches must be [B,H,W,3], got %s" % (tuple(images.shape),))
+        if not pinned and getattr(images, "dtype", None) in (np.uint8, torch.uint8):
+            images = self._resident_float(images)
         x = images if pinned else _h.to_dev(images)
         self.base_model._ensure(x.shape[0])            # the replicas inherit the base model's kernel table
         if self.lanes >= 2 and not self._lanes_calibrated:
             for k in range(self.lanes):
                 self._lane(k)
-            xcal = _h.to_dev(x) if pinned else x          # (the one-off lane check runs on a resident copy)
+            # (the one-off lane check runs on a resident copy)
+            xcal = self._resident_float(x) if u8 else (_h.to_dev(x) if pinned else x)
             if self.calibrate and self.lanes == 2:
                 self._calibrate_lane_streams(xcal)
             else:
@@ -242,14 +251,26 @@ class DecoderModel(object):
         m, st = self._lane(i)
         if pinned:
             # per-lane device buffer: the copy of step n + lanes into it is ordered behind step n's kernels on the same stream
-            buf = self._lane_inputs.get(i)
+            buf = self._lane_inputs.get((i, x.dtype))
             if buf is None or buf.shape[0] < x.shape[0] or buf.shape[1:] != x.shape[1:]:
                 buf = torch.empty((max(x.shape[0], getattr(self.base_model, "_max_batch", 0) or 0),) + tuple(x.shape[1:]),
-                                  dtype=torch.float32, device=_h.device())
-                self._lane_inputs[i] = buf
+                                  dtype=x.dtype, device=_h.device())
+                self._lane_inputs[(i, x.dtype)] = buf
             with torch.cuda.stream(st):
                 xd = buf[:x.shape[0]]
                 xd.copy_(x, non_blocking=True)
+                if u8:
+                    S = int(self.base_model.img_size)
+                    fb = self._lane_inputs.get((i, "f32"))
+                    if fb is None or fb.shape[0] < x.shape[0] or fb.shape[1] != S:
+                        fb = torch.empty((max(x.shape[0], getattr(self.base_model, "_max_batch", 0) or 0), S, S, 3),
+                                         dtype=torch.float32, device=_h.device())
+                        self._lane_inputs[(i, "f32")] = fb
+                    xf = fb[:x.shape[0]]
+                    _h.check(_h.lib().ssd_preprocess(_h.ptr(xd), int(x.shape[0]), int(x.shape[1]), int(x.shape[2]), 3, S, S,
+                                                     _h.ptr(xf), _h.vp(st.cuda_stream)), "submit: ssd_preprocess")
+                    xd.record_stream(st)
+                    xd = xf
             x = xd
         elif sync_input:
             st.wait_stream(torch.cuda.current_stream())
@@ -260,6 +281,11 @@ class DecoderModel(object):
             t.record_stream(st)
         d.last_valid_detections = v
         return b, l, s
+
+    def _resident_float(self, images_u8):
+        from utils import data_utils
+        S = int(self.base_model.img_size)
+        return data_utils.preprocess_batch(images_u8, S, S)
 
     def close(self):
         """Release the lanes: their replicas of the net (arena, scratch); their streams go back to the process-wide
@@ -290,6 +316,8 @@ class DecoderModel(object):
 
     def __call__(self, images):
         d = self.decoder
+        if getattr(images, "dtype", None) in (np.uint8, torch.uint8) and hasattr(self.base_model, "img_size"):
+            images = self._resident_float(images)       # uint8 [B,H,W,3]: convert + resize on the GPU (ssd_preprocess)
         if hasattr(self.base_model, "predict_on_device"):
             b, l, s, v = self.base_model.predict_on_device(
                 images, d.prior_boxes, d.variances, max_total=d.max_total_size,
