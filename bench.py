@@ -78,6 +78,8 @@ def main():
     ap.add_argument("--no-other-leg", action="store_true", help="skip the informational second mode (two lanes / one lane)")
     ap.add_argument("--no-overlap", action="store_true", help="profiling runs: no intra-step side streams (option overlap_heads 0), so per-kernel durations are uncontended")
     ap.add_argument("--layers", action="store_true", help="also print the per-layer table to stderr")
+    ap.add_argument("--opt", action="append", default=[], metavar="NAME=VALUE",
+                    help="diagnostics / A-B runs: a net option (ssd_net_set_option) set before finalize, e.g. --opt image_ticket=1; recorded in config.options")
     ap.add_argument("--train", action="store_true", help="time the training step (SURVEY 8f N1) instead of inference")
     ap.add_argument("--no-h2d", dest="h2d", action="store_false",
                     help="skip the separately labelled leg that feeds the K steps from pinned HOST batches (PCIe-inclusive; never `value`)")
@@ -161,6 +163,9 @@ def main():
     model = get_model(hp, max_batch=B, precision="bf16" if args.dtype == "bf16" else "fp32")
     if args.no_overlap:
         model.set_option("overlap_heads", 0)
+    for o in args.opt:
+        k, v = o.split("=", 1)
+        model.set_option(k, int(v))
     weights = data_utils.synthetic_weights(model, seed=1)
     priors = bbox_utils.generate_prior_boxes(hp["feature_map_shapes"], hp["aspect_ratios"])
     decoder_model = get_decoder_model(model, priors, hp, lanes=args.lanes)
@@ -401,7 +406,7 @@ def main():
                        "" if (args.dtype == "bf16") == (hp["img_size"] != 300) else " shape, in %s" % args.dtype),
                    "global_batch": world * B, "priors": model.num_priors, "labels": hp["total_labels"],
                    "mean_detections_per_image": mean_det, "nms_active": mean_det > 0, "parallelism": "batch-sharded x%d, no collective" % world,
-                   "batches_in_flight_per_gpu": args.lanes,
+                   "batches_in_flight_per_gpu": args.lanes, "options": dict(getattr(model, "_options", {})),
                    "lane_calibration": getattr(decoder_model, "lane_calibration", None),
                    # where the kernel choices came from (tuning.py): a shipped table = nothing timed on the
                    # device = the same kernels and bits in every process
