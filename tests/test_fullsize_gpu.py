@@ -322,6 +322,42 @@ def test_two_lanes_match_one_lane():
             np.testing.assert_array_equal(a.cpu().numpy(), b)
 
 
+def test_lane_check_retries_on_fresh_streams(monkeypatch):
+    """Where the lanes do not pay on the streams they got (which hardware queue a stream lands on depends on what the
+    process created before), ``DecoderModel`` repeats its check on fresh streams before it falls back to one lane: a
+    first check forced to fail must be followed by a second one on OTHER streams, and the results stay those of the
+    one-at-a-time path bit for bit."""
+    from models import decoder as dec
+    from models.ssd_mobilenet_v2 import get_model
+    from utils import bbox_utils
+    hp = helpers.hyper_params("mobilenet_v2")
+    m = get_model(hp, max_batch=4)
+    m.set_weights(helpers.synthetic_weights("mobilenet_v2", hp))
+    priors = bbox_utils.generate_prior_boxes(hp["feature_map_shapes"], hp["aspect_ratios"])
+    dm1 = dec.get_decoder_model(m, priors, hp, lanes=1)
+    dm3 = dec.get_decoder_model(m, priors, hp, lanes=3)
+    seen = []
+    real = dec.DecoderModel._check_lanes_pay_once
+
+    def once(self, x):
+        real(self, x)
+        seen.append([st.cuda_stream for st in self._lane_streams])
+        if len(seen) == 1:
+            self._lanes_active = False              # pretend the first set of streams shared a hardware queue
+
+    monkeypatch.setattr(dec.DecoderModel, "_check_lanes_pay_once", once)
+    batches = [helpers.images(4, 300, seed=70 + i) for i in range(4)]
+    ref = [tuple(t.cpu().numpy() for t in dm1(b)) for b in batches]
+    outs = [dm3.submit(b) for b in batches]
+    dm3.wait()
+    torch.cuda.synchronize()
+    assert len(seen) >= 2 and not set(seen[0]) & set(seen[1])
+    assert len(dm3.lane_calibration["attempts_ms_per_step"]) == len(seen)
+    for o, r in zip(outs, ref):
+        for a, b in zip(o, r):
+            np.testing.assert_array_equal(a.cpu().numpy(), b)
+
+
 def test_uint8_pinned_batches_are_converted_on_the_lane():
     """``DecoderModel.submit`` of a PINNED UINT8 batch [B,H,W,3] (the reference's images before ``preprocessing``,
     utils/data_utils.py:17-22): the lane copies the bytes (a quarter of the float batch over PCIe), runs
