@@ -9,6 +9,21 @@ import subprocess
 import sys
 
 REPO = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+W12 = [("mbv2 head1", 64, 19, 576, 100, 3, "mfma3_2x7_8x1", 5), ("mbv2 head1", 64, 19, 576, 100, 3, "mfma3_1x7_12x1", 5),
+       ("mbv2 head1", 64, 19, 576, 100, 3, "mfma3_1x7_12x1", 3), ("mbv2 head1", 64, 19, 576, 100, 3, "mfma3_2x4_6x2", 3), ("mbv2 head1", 64, 19, 576, 100, 3, "mfma3_2x4_6x2", 2),
+       ("mbv2 head2", 64, 10, 1280, 150, 3, "mfma3_4x5_4x2", 10), ("mbv2 head2", 64, 10, 1280, 150, 3, "mfma3_2x5_6x2", 8), ("mbv2 head2", 64, 10, 1280, 150, 3, "mfma3_2x5_6x2", 4),
+       ("mbv2 Conv_1", 64, 10, 320, 1280, 1, "mfma3_4x4_2x4", 1), ("mbv2 Conv_1", 64, 10, 320, 1280, 1, "mfma3_2x4_6x2", 1), ("mbv2 Conv_1", 64, 10, 320, 1280, 1, "mfma3_4x2_3x4", 1),
+       ("mbv2 Conv_1", 64, 10, 320, 1280, 1, "mfma3_3x4_4x3", 1),
+       ("vgg conv4_2", 32, 38, 512, 512, 3, "mfma3_4x4_4x2", 1), ("vgg conv4_2", 32, 38, 512, 512, 3, "mfma3_2x4_6x2", 1), ("vgg conv4_2", 32, 38, 512, 512, 3, "mfma3_4x2_3x4", 1),
+       ("vgg conv4_2", 32, 38, 512, 512, 3, "mfma3_3x4_4x3", 1),
+       ("vgg conv3_2", 32, 75, 256, 256, 3, "mfma3_4x4_4x2", 1), ("vgg conv3_2", 32, 75, 256, 256, 3, "mfma3_2x4_6x2", 1), ("vgg conv3_2", 32, 75, 256, 256, 3, "mfma3_4x2_3x4", 1),
+       ("vgg conv2_2", 32, 150, 128, 128, 3, "mfma3_4x4_4x2", 1), ("vgg conv2_2", 32, 150, 128, 128, 3, "mfma3_2x4_6x2", 1), ("vgg conv2_2", 32, 150, 128, 128, 3, "mfma3_4x2_3x4", 1),
+       ("vgg conv1_2", 32, 300, 64, 64, 3, "mfma3_4x2_4x2", 1), ("vgg conv1_2", 32, 300, 64, 64, 3, "mfma3_2x4_6x2", 1), ("vgg conv1_2", 32, 300, 64, 64, 3, "mfma3_4x2_3x4", 1),
+       ("vgg fc7", 32, 19, 1024, 1024, 1, "mfma3_4x4_4x2", 1), ("vgg fc7", 32, 19, 1024, 1024, 1, "mfma3_2x4_6x2", 1), ("vgg fc7", 32, 19, 1024, 1024, 1, "mfma3_3x4_4x3", 1),
+       ("mbv2 head1", 64, 19, 576, 100, 3, "mfma3_1x7_16x1", 5), ("mbv2 head1", 64, 19, 576, 100, 3, "mfma3_2x4_8x2", 5), ("mbv2 head1", 64, 19, 576, 100, 3, "mfma3_2x4_8x2", 3),
+       ("mbv2 head2", 64, 10, 1280, 150, 3, "mfma3_2x5_8x2", 10), ("mbv2 Conv_1", 64, 10, 320, 1280, 1, "mfma3_2x4_8x2", 1),
+       ("vgg conv4_2", 32, 38, 512, 512, 3, "mfma3_2x4_8x2", 1), ("vgg conv3_2", 32, 75, 256, 256, 3, "mfma3_2x4_8x2", 1), ("vgg conv2_2", 32, 150, 128, 128, 3, "mfma3_2x4_8x2", 1),
+       ("vgg conv1_2", 32, 300, 64, 64, 3, "mfma3_2x4_8x2", 1), ("vgg fc7", 32, 19, 1024, 1024, 1, "mfma3_2x4_8x2", 1)]
 SHAPES = [("mbv2 head1", 64, 19, 576, 100, 3, "mfma3_2x7_8x1", 5), ("mbv2 head1", 64, 19, 576, 100, 3, "mfma3_2x7_4x1", 3),
           ("mbv2 head1", 64, 19, 576, 100, 3, "mfma3_2x7_4x1", 2),
           ("mbv2 head2", 64, 10, 1280, 150, 3, "mfma3_4x5_4x2", 10), ("mbv2 head2", 64, 10, 1280, 150, 3, "mfma3_4x5_2x2", 5),
@@ -30,7 +45,7 @@ def child():
     lib = h.lib()
     names = [lib.ssd_conv_config_name(c).decode() for c in range(lib.ssd_conv_num_configs())]
     out = {}
-    for name, B, H, Cin, Cout, k, cfg, split in SHAPES:
+    for name, B, H, Cin, Cout, k, cfg, split in (W12 if os.environ.get("C3_SHAPES") == "w12" else SHAPES):
         pad = (k - 1) // 2
         d = h.ConvDesc(B, H, H, Cin, Cout, k, k, 1, 1, pad, pad, pad, pad, 0, 0)
         torch.manual_seed(0)
@@ -65,6 +80,9 @@ if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "child":
         child()
         sys.exit(0)
+    if "w12" in sys.argv:           # the 12-wave tiles against the 8-wave ones (production library)
+        sys.argv.remove("w12")
+        os.environ["C3_SHAPES"] = "w12"
     variants = [int(v) for v in sys.argv[1:]] or [0]
     rows = {}
     for v in variants:

@@ -43,6 +43,12 @@ const Conv3Cfg kCfg3[] = {
     C3CFG(4, 2, 4, 2),    // 256 x 64
     C3CFG(2, 7, 8, 1),    // 256 x 112
     C3CFG(4, 5, 4, 2),    // 256 x 160
+    // 12 / 16 waves (three / four per SIMD; the middle group runs its MFMAs between its stores and its loads): no faster per
+    // K tile than the 8-wave tiles (profiles/HISTORY.md, round 4), but 192-row tiles fit some grids in fewer rounds of workgroups
+    // (head level 1 at B = 64: 121 tiles x split-K 2 = 242 workgroups, 184 -> 151 us; VGG fc7 158 -> 137 us)
+    C3CFG(2, 4, 6, 2),    // 192 x 128, 12 waves
+    C3CFG(3, 4, 4, 3),    // 192 x 192, 12 waves
+    C3CFG(2, 4, 8, 2),    // 256 x 128, 16 waves (118 registers)
 };
 constexpr int kNumCfg3 = sizeof(kCfg3) / sizeof(kCfg3[0]);
 int c3_lds_bytes(const Conv3Cfg& g, int planes) {

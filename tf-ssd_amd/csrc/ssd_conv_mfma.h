@@ -44,7 +44,8 @@ __device__ __forceinline__ void conv_mfma_body(const ConvParams& p, float* __res
     constexpr int XU = BM * UPR, WU = BN * UPR;
     constexpr int NTHR = 64 * WM * WN;          // 256; the split-bf16 tiles also come with 8 waves
     constexpr int XP = (XU + NTHR - 1) / NTHR, WP = (WU + NTHR - 1) / NTHR;
-    static_assert(NTHR == 256 || (SPLIT3 && NTHR == 512), "4 waves per block (8: split-bf16 only)");
+    static_assert(NTHR == 256 || (SPLIT3 && (NTHR == 512 || NTHR == 768 || NTHR == 1024)),
+                  "4 waves per block (8 / 12 / 16: split-bf16 and bf16 tiles only)");
     // two LDS stages: tile kt+1 is written while tile kt is multiplied -> one barrier per K tile
     // (fp32: 2 * (BM + BN) * LDK floats; split-bf16: 2 stages x 3 planes x (BM + BN) rows of 32 bf16 = 64 bytes)
     constexpr int STAGE_FLOATS = SPLIT3 ? (BM + BN) * 16 * NP : (BM + BN) * LDK;
@@ -229,8 +230,17 @@ __device__ __forceinline__ void conv_mfma_body(const ConvParams& p, float* __res
 #pragma unroll
     for (int kc = 0; kc < BK / 16; ++kc)
         fcol[kc] = SWZ ? (((kc * 4 + (lane >> 4)) ^ (BK == 32 ? (frow >> 1) & 7 : frow)) << 2) : kc * 16 + fk;
+#ifdef SSD_C3_PROF
+    long long c3tp[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    long long c3t0 = clock64();
+#endif
 #ifndef SSD_C3_VARIANT
 #define SSD_C3_VARIANT 0      // experiments (tools/r4/build_c3var.sh + tests/micro/conv3_variants.py); 0 = the production kernel
+#endif
+#ifdef SSD_C3_PROF            // diagnostics (tests/micro/conv3_prof.py): per-wave cycles of the loop's phases, dumped by one workgroup
+#define C3T(i) do { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); const long long t_ = clock64(); c3tp[i] += t_ - c3t0; c3t0 = t_; } while (0)
+#else
+#define C3T(i) do {} while (0)
 #endif
 #ifndef SSD_C3_ABLATE
 #define SSD_C3_ABLATE 0       // diagnostics (tests/micro/conv3_ablate.py): 1 no MFMA, 2 no fragment reads, 4 no split, 8 no global loads, 16 no LDS stores
@@ -265,6 +275,33 @@ __device__ __forceinline__ void conv_mfma_body(const ConvParams& p, float* __res
         auto store3 = [&](int stage, const f32x4 (&X)[XP], const bf16x8 (&W)[WP3], const unsigned vm) {
             char* Xs = reinterpret_cast<char*>(smem + stage * STAGE_FLOATS);
             char* Ws = Xs + NP * BM * 64;
+#ifdef SSD_C3_PROF
+            if constexpr (NP == 3 && XU % NTHR == 0 && WU3 % NTHR == 0) {      // phases timed apart: load wait / split / store issue / drain
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                C3T(5);
+                uint2 hh[XP], mm[XP], ll[XP];
+#pragma unroll
+                for (int ps = 0; ps < XP; ++ps) {
+                    const f32x4 v = (GEMM1X1 || ((vm >> ps) & 1u)) ? X[ps] : f32x4{0.f, 0.f, 0.f, 0.f};
+                    split4(v, hh[ps], mm[ps], ll[ps]);
+                    asm volatile("" : "+v"(hh[ps]), "+v"(mm[ps]), "+v"(ll[ps]));
+                }
+                C3T(6);
+#pragma unroll
+                for (int ps = 0; ps < XP; ++ps) {
+                    char* d = Xs + ((tid + ps * NTHR) / UPR) * 64 + xcol;
+                    *reinterpret_cast<uint2*>(d) = hh[ps];
+                    *reinterpret_cast<uint2*>(d + BM * 64) = mm[ps];
+                    *reinterpret_cast<uint2*>(d + 2 * BM * 64) = ll[ps];
+                }
+#pragma unroll
+                for (int ps = 0; ps < WP3; ++ps) *reinterpret_cast<bf16x8*>(Ws + w3dst[ps]) = W[ps];
+                asm volatile("" ::: "memory");
+                { const long long t_ = clock64(); c3tp[7] += t_ - c3t0; c3t0 = t_; }      // issue only (no lgkmcnt wait)
+                C3T(8);                                                                  // drain
+                return;
+            }
+#endif
 #pragma unroll
             for (int ps = 0; ps < XP; ++ps) {
                 const int u = tid + ps * NTHR;
@@ -353,7 +390,12 @@ __device__ __forceinline__ void conv_mfma_body(const ConvParams& p, float* __res
         // one wave multiplies while the other splits / stores the next tile, with one barrier per tile as before
         // (a stage is written one iteration after its last read and read one iteration after its last write by
         // either group).  Both groups hold tile kt + 1 in registers when iteration kt starts.
-        const bool late = NTHR == 512 && __builtin_amdgcn_readfirstlane(tid >> 6) >= 4;
+        // 12 waves (three per SIMD): a third group runs its MFMAs between its stores and its loads -- the three waves of a SIMD
+        // are in three different phases, and a wave's serial chain (MFMAs + staging; profiles/HISTORY.md, cycle timeline) is a
+        // third shorter per unit of tile
+        const int wgrp = NTHR > 256 ? __builtin_amdgcn_readfirstlane(tid >> 6) >> 2 : 0;
+        const bool late = NTHR > 256 && wgrp == (NTHR == 512 ? 1 : 2);
+        const bool mid = NTHR >= 768 && wgrp == 1;                       // (16 waves: the fourth group runs in the first one's order)
         if (kt_begin < kt_end) {
             tile_setup(kt_begin);
             load3(xs0, ws0, vm0);
@@ -436,14 +478,18 @@ __device__ __forceinline__ void conv_mfma_body(const ConvParams& p, float* __res
 #endif
         for (int kt = kt_begin; kt < kt_end; ++kt) {
             const int stage = (kt - kt_begin) & 1;
-            if (!late) mma_tile(stage);
+            if (!late && !mid) { mma_tile(stage); C3T(0); }
             if (kt + 1 < kt_end) store3(stage ^ 1, xs0, ws0, vm0);
+            C3T(1);
+            if (NTHR >= 768 && mid) mma_tile(stage);
             if (kt + 2 < kt_end) {
                 tile_advance();
                 load3(xs0, ws0, vm0);          // in flight across the barrier and the next tile's MFMAs
             }
-            if (late) mma_tile(stage);
+            C3T(2);
+            if (late) { mma_tile(stage); C3T(3); }
             __syncthreads();
+            C3T(4);
         }
     } else {
     if (kt_begin < kt_end) {
@@ -590,6 +636,16 @@ __device__ __forceinline__ void conv_mfma_body(const ConvParams& p, float* __res
             }
         }
     }
+#ifdef SSD_C3_PROF
+    if constexpr (SPLIT3) {
+        __syncthreads();
+        if (blockIdx.x == gridDim.x / 3 && lane == 0 && p.split_k <= 1) {
+            float* d = p.out + m0 * p.out_pixel_stride + n0 + wave * 12;
+            for (int i = 0; i < 9; ++i) d[i] = (float)c3tp[i];
+            d[9] = (float)(kt_end - kt_begin);
+        }
+    }
+#endif
 }
 
 
