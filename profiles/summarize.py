@@ -39,6 +39,23 @@ if stats:
     for k, (n, us) in sorted(fam.items(), key=lambda kv: -kv[1][1]):
         print("%-40s %8d %12.1f %12.2f %6.1f%%" % (k, n, us, us / max(n, 1), 100 * us / tot))
 
+# one kernel template may serve several layers (conv tiles): the same table split by launch grid, from the kernel trace
+trace = find("*kernel_trace.csv") if stats else None
+if trace and os.path.dirname(trace) == os.path.dirname(stats):
+    by = defaultdict(lambda: [0, 0.0])
+    for r in csv.DictReader(open(trace)):
+        n = short(r["Kernel_Name"])
+        if not n.startswith(("conv_mfma3_kernel", "conv_mfma_kernel", "conv_bf16_kernel", "conv_wino_kernel", "(anonymous namespace)::conv_skinny_kernel")):
+            continue
+        wg = int(r["Workgroup_Size_X"])
+        key = (n, "%d x %d workgroups of %d" % (int(r["Grid_Size_X"]) // wg, int(r["Grid_Size_Y"]), wg))
+        by[key][0] += 1
+        by[key][1] += (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
+    print("\n== dense-conv tile kernels by launch grid (a template serves several layers; avg_us per grid = per layer)")
+    print("%-64s %-34s %6s %10s" % ("kernel", "grid", "calls", "avg_us"))
+    for (n, g), (c, us) in sorted(by.items(), key=lambda kv: -kv[1][1])[:24]:
+        print("%-64s %-34s %6d %10.2f" % (n.replace("(anonymous namespace)::", "").split("(")[0][:64], g, c, us / c))
+
 traffic = {}      # family -> {counter: KB per launch as reported}
 for tag, counter in (("pmc_fetch", "FETCH_SIZE"), ("pmc_write", "WRITE_SIZE")):
     f = find(os.path.join(tag, "**", "*counter_collection.csv")) or find("*%s*counter_collection.csv" % tag[4])
