@@ -251,18 +251,28 @@ __device__ __forceinline__ void conv_mfma_body(const ConvParams& p, float* __res
         f32x4 xs0[XP];
         bf16x8 ws0[WP3];
         unsigned vm0 = 0;
+        // general path: the pixels come through a raw BUFFER load whose range ends with the input tensor -- a padded /
+        // out-of-range tap reads offset 2^31 (beyond the range) and the hardware returns zeros: no per-element select when the
+        // tile is written (16 v_cndmask per thread and K tile; the loop's time is its MFMAs PLUS its other instructions)
+        constexpr bool BUFZ = !GEMM1X1;
+        const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<char*>(xbase), 0,
+            (int)(unsigned)min((long)0xffffffffL, (long)(reinterpret_cast<const char*>(p.in + (long)p.B * p.H * p.W * p.Cin) - xbase)),
+            0x00020000);
         auto load3 = [&](f32x4 (&X)[XP], bf16x8 (&W)[WP3], unsigned& vm) {      // the tile described by the l_* state
             vm = 0;
             if (SSD_C3_ABLATE & 8) return;
 #pragma unroll
             for (int ps = 0; ps < XP; ++ps) {
                 const bool ok = x_is_valid(ps);
-                vm |= (ok ? 1u : 0u) << ps;
                 if (GEMM1X1) {
+                    vm |= (ok ? 1u : 0u) << ps;
                     X[ps] = f32x4{0.f, 0.f, 0.f, 0.f};
                     if (ok) X[ps] = *reinterpret_cast<const f32x4*>(xrow1[ps] + l_k0);
                 } else {
-                    X[ps] = *reinterpret_cast<const f32x4*>(xbase + (unsigned)(ok ? xoff[ps] + l_xtile : 0));
+                    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+                    const u32x4 r = __builtin_amdgcn_raw_buffer_load_b128(xrsrc, ok ? xoff[ps] + l_xtile : (int)0x80000000, 0, 0);
+                    X[ps] = __builtin_bit_cast(f32x4, r);
                 }
             }
 #pragma unroll
@@ -282,7 +292,7 @@ __device__ __forceinline__ void conv_mfma_body(const ConvParams& p, float* __res
                 uint2 hh[XP], mm[XP], ll[XP];
 #pragma unroll
                 for (int ps = 0; ps < XP; ++ps) {
-                    const f32x4 v = (GEMM1X1 || ((vm >> ps) & 1u)) ? X[ps] : f32x4{0.f, 0.f, 0.f, 0.f};
+                    const f32x4 v = (GEMM1X1 || BUFZ || ((vm >> ps) & 1u)) ? X[ps] : f32x4{0.f, 0.f, 0.f, 0.f};
                     split4(v, hh[ps], mm[ps], ll[ps]);
                     asm volatile("" : "+v"(hh[ps]), "+v"(mm[ps]), "+v"(ll[ps]));
                 }
@@ -306,7 +316,7 @@ __device__ __forceinline__ void conv_mfma_body(const ConvParams& p, float* __res
             for (int ps = 0; ps < XP; ++ps) {
                 const int u = tid + ps * NTHR;
                 if (XU % NTHR == 0 || u < XU) {
-                    const f32x4 v = (GEMM1X1 || ((vm >> ps) & 1u)) ? X[ps] : f32x4{0.f, 0.f, 0.f, 0.f};
+                    const f32x4 v = (GEMM1X1 || BUFZ || ((vm >> ps) & 1u)) ? X[ps] : f32x4{0.f, 0.f, 0.f, 0.f};
                     char* d = Xs + (u / UPR) * 64 + xcol;
                     if constexpr (NP == 1) {
                         *reinterpret_cast<uint2*>(d) = rne4(v);
