@@ -166,6 +166,16 @@ __device__ __forceinline__ void conv_mfma_body(const ConvParams& p, float* __res
         return (xvalid[ps] >> l_tap) & 1u;
     };
 
+    // general path: the pixels come through a raw BUFFER load whose range ends with the input tensor -- a padded /
+    // out-of-range tap reads offset 2^31 (beyond the range) and the hardware returns zeros: no per-element select when the
+    // tile is written (16 v_cndmask per thread and K tile; the loop's time is its MFMAs PLUS its other instructions:
+    // split-bf16 tiles -5 .. -10 %, profiles/HISTORY.md round 4)
+    constexpr bool BUFZ = !GEMM1X1;
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<char*>(xbase), 0,
+        (int)(unsigned)min((long)0xffffffffL, (long)(reinterpret_cast<const char*>(p.in + (long)p.B * p.H * p.W * p.Cin) - xbase)),
+        0x00020000);
     f32x4 xr[XP], wr[WP];
     auto load_tile = [&]() {                   // the tile described by the l_* state
         if (SSD_CONV_ABLATE & 1) return;
@@ -175,8 +185,8 @@ __device__ __forceinline__ void conv_mfma_body(const ConvParams& p, float* __res
                 xr[ps] = f32x4{0.f, 0.f, 0.f, 0.f};
                 if (x_is_valid(ps)) xr[ps] = *reinterpret_cast<const f32x4*>(xrow1[ps] + l_k0);
             } else {
-                const int off = x_is_valid(ps) ? xoff[ps] + l_xtile : 0;
-                xr[ps] = *reinterpret_cast<const f32x4*>(xbase + (unsigned)off);     // valid offsets are >= 0: SGPR base + u32 offset
+                const u32x4 r = __builtin_amdgcn_raw_buffer_load_b128(xrsrc, x_is_valid(ps) ? xoff[ps] + l_xtile : (int)0x80000000, 0, 0);
+                xr[ps] = __builtin_bit_cast(f32x4, r);      // valid offsets are >= 0: SGPR base + u32 offset
             }
         }
 #pragma unroll
@@ -208,7 +218,7 @@ __device__ __forceinline__ void conv_mfma_body(const ConvParams& p, float* __res
             const int u = tid + ps * NTHR;
             if (XU % NTHR == 0 || u < XU)
                 *reinterpret_cast<f32x4*>(Xs + (u / UPR) * LDK + st_col) =
-                    (GEMM1X1 || x_is_valid(ps)) ? xr[ps] : f32x4{0.f, 0.f, 0.f, 0.f};
+                    (GEMM1X1 || BUFZ || x_is_valid(ps)) ? xr[ps] : f32x4{0.f, 0.f, 0.f, 0.f};
         }
 #pragma unroll
         for (int ps = 0; ps < WP; ++ps) {
@@ -251,14 +261,6 @@ __device__ __forceinline__ void conv_mfma_body(const ConvParams& p, float* __res
         f32x4 xs0[XP];
         bf16x8 ws0[WP3];
         unsigned vm0 = 0;
-        // general path: the pixels come through a raw BUFFER load whose range ends with the input tensor -- a padded /
-        // out-of-range tap reads offset 2^31 (beyond the range) and the hardware returns zeros: no per-element select when the
-        // tile is written (16 v_cndmask per thread and K tile; the loop's time is its MFMAs PLUS its other instructions)
-        constexpr bool BUFZ = !GEMM1X1;
-        const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(
-            const_cast<char*>(xbase), 0,
-            (int)(unsigned)min((long)0xffffffffL, (long)(reinterpret_cast<const char*>(p.in + (long)p.B * p.H * p.W * p.Cin) - xbase)),
-            0x00020000);
         auto load3 = [&](f32x4 (&X)[XP], bf16x8 (&W)[WP3], unsigned& vm) {      // the tile described by the l_* state
             vm = 0;
             if (SSD_C3_ABLATE & 8) return;
@@ -270,7 +272,6 @@ __device__ __forceinline__ void conv_mfma_body(const ConvParams& p, float* __res
                     X[ps] = f32x4{0.f, 0.f, 0.f, 0.f};
                     if (ok) X[ps] = *reinterpret_cast<const f32x4*>(xrow1[ps] + l_k0);
                 } else {
-                    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
                     const u32x4 r = __builtin_amdgcn_raw_buffer_load_b128(xrsrc, ok ? xoff[ps] + l_xtile : (int)0x80000000, 0, 0);
                     X[ps] = __builtin_bit_cast(f32x4, r);
                 }
