@@ -174,7 +174,9 @@ __device__ __forceinline__ void conv_mfma_body(const ConvParams& p, float* __res
     typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
     const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<char*>(xbase), 0,
-        (int)(unsigned)min((long)0xffffffffL, (long)(reinterpret_cast<const char*>(p.in + (long)p.B * p.H * p.W * p.Cin) - xbase)),
+        // (a tile's own offsets are within a few images of xbase; the range is capped below 2^31 so that the zero-fill offset
+        // stays out of range for tensors of any size)
+        (int)min((long)0x7fffffffL, (long)(reinterpret_cast<const char*>(p.in + (long)p.B * p.H * p.W * p.Cin) - xbase)),
         0x00020000);
     f32x4 xr[XP], wr[WP];
     auto load_tile = [&]() {                   // the tile described by the l_* state
