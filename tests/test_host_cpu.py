@@ -387,3 +387,21 @@ def test_make_tf_golden_tool_stays_runnable():
     consumer = open(os.path.join(REPO, "tests", "test_tf_golden.py")).read()
     read = set(re.findall(r'_tf\("(tf_[a-z_%]+\.npz)"', consumer))
     assert written == read and len(written) >= 6, (written, read)
+
+
+def test_shipped_kernel_tables_were_measured_at_this_build():
+    """Every table under tf-ssd_amd/tables/ records the ``ssd_build_id()`` it was measured on; the id is a hash of the
+    kernel sources, the public header and the compile flags (csrc/build.sh, bench.build_id_from_sources).  A kernel
+    change without re-measured tables would pin choices that are still valid but possibly slower, and the bench line
+    would report ``kernel_table.stale``: caught here, without a GPU."""
+    import glob
+    import bench
+    want = bench.build_id_from_sources()
+    tables = sorted(glob.glob(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tf-ssd_amd", "tables", "*.tune")))
+    assert len(tables) >= 20
+    stale = []
+    for t in tables:
+        head = [l for l in open(t).read().splitlines() if l.startswith("#build=")]
+        if not head or head[0].split("=", 1)[1] != want:
+            stale.append(os.path.basename(t))
+    assert not stale, "tables measured at another build than %s (re-run tools/make_tuning_tables.py): %s" % (want, stale[:4])
