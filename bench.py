@@ -208,13 +208,21 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item())
 
-    def timed(dm, lanes, repeats=1):
+    local_regions = []
+
+    def timed(dm, lanes, repeats=1, keep_local=False):
         """W untimed warm-up steps, then `repeats` timed regions of K steps each (a 20-step region is ~27 ms: one
         region alone is at the mercy of a clock ramp).  Every region's time is the MAX over ranks; returns all."""
         run_steps(dm, max(args.warmup, 2 * lanes), lanes)
-        return [reduce_max(region(dm, lanes)) for _ in range(max(1, repeats))]
+        out = []
+        for _ in range(max(1, repeats)):
+            t = region(dm, lanes)
+            if keep_local:
+                local_regions.append(t)
+            out.append(reduce_max(t))
+        return out
 
-    regions = timed(decoder_model, args.lanes, args.repeats)
+    regions = timed(decoder_model, args.lanes, args.repeats, keep_local=True)
     elapsed = sorted(regions)[len(regions) // 2]            # the median region is the headline
     # the other mode beside it (informational): two batches in flight when the headline is one step at a time,
     # one step at a time when the headline keeps two in flight
@@ -467,6 +475,8 @@ def main():
         "gpu_ms_per_step_sum": total_ms,
     }
 
+    if dist is not None:
+        result["multi_gpu"] = ranks_report(dist, sorted(local_regions)[len(local_regions) // 2], args.steps)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(args.backbone, hp, weights, priors.cpu().numpy(), args.cpu_sample)
     decoder_model.close()
@@ -504,6 +514,7 @@ def train_bench(args, hp, get_model, rank, world, dist):
         loc, conf = step()
     first = float((loc + conf).mean().item())
     regions = []
+    local_regions = []
     for _ in range(max(1, args.repeats)):                     # K steps per region, barrier + synchronize on both sides
         torch.cuda.synchronize()
         if dist is not None:
@@ -517,6 +528,7 @@ def train_bench(args, hp, get_model, rank, world, dist):
             dist.barrier()
         torch.cuda.synchronize()
         e = time.perf_counter() - t0
+        local_regions.append(e)
         if dist is not None:
             t = torch.tensor([e], dtype=torch.float64, device="cuda")
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -589,7 +601,24 @@ def train_bench(args, hp, get_model, rank, world, dist):
         result["cpu_baseline"] = {"value": n * passes / dt, "unit": "images/sec", "cores": threads, "host_cores": os.cpu_count(),
                                   "kind": "port", "sample": "%d passes of the oracle's forward + loss + backward on %d images (torch-CPU "
                                   "autograd, no optimiser step; TensorFlow itself is not installable here)" % (passes, n)}
+    if dist is not None:
+        result["multi_gpu"] = ranks_report(dist, sorted(local_regions)[len(local_regions) // 2], args.steps)
     emit(result, rank, dist)
+
+
+def ranks_report(dist, local_region_s, steps):
+    """N > 1 (or --force-dist) lines say what the collective actually saw: `ranks_seen` = an all-reduce (SUM) of ones
+    over RCCL -- it equals n_gpus only if every rank took part -- and the spread of the per-rank median region time
+    (the headline takes the MAX over ranks of every region)."""
+    import torch
+    ones = torch.ones(1, dtype=torch.float64, device="cuda")
+    dist.all_reduce(ones, op=dist.ReduceOp.SUM)
+    lo = torch.tensor([local_region_s], dtype=torch.float64, device="cuda")
+    hi = lo.clone()
+    dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+    dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+    return {"ranks_seen": int(round(float(ones.item()))), "world_size": dist.get_world_size(), "backend": dist.get_backend(),
+            "ms_per_step_rank_min": 1e3 * float(lo.item()) / steps, "ms_per_step_rank_max": 1e3 * float(hi.item()) / steps}
 
 
 def emit(result, rank, dist):

@@ -80,10 +80,95 @@ def synthetic_weights(backbone, hp=None, seed=1, target_frac=0.05):
             w[name] = np.full(shape, 20.0, np.float32)
         else:  # bias
             w[name] = rng.uniform(-0.05, 0.05, shape).astype(np.float32)
-    # tame the head logits, then calibrate the background bias
+    _calibrate_heads(w, backbone, hp, target_frac)
+    _WCACHE[key] = w
+    return w
+
+
+RESIDUAL_BLOCKS = (2, 4, 5, 7, 8, 9, 11, 12, 14, 15)       # MobileNetV2 blocks with `x + project(...)` (stride 1, Cin == Cout)
+
+
+def trained_like_weights(backbone, hp=None, seed=11, target_frac=0.05, calib_images=4):
+    """A second seeded weight set with the CONDITIONING of a trained net.  ``synthetic_weights`` draws
+    He-normal kernels and BatchNorm statistics that have nothing to do with the activations they normalise: every
+    residual branch then has unit gain, a relative perturbation grows ~1.3x per block (x33 through MobileNetV2's 16
+    blocks) and the bf16 mode can only be held to a multiple of that amplification.  Here (a) every BatchNorm's moving
+    mean / variance ARE the statistics of its input over ``calib_images`` seeded images (one training-mode pass of the
+    oracle's torch-CPU graph: what training leaves behind), so activations stay O(1) through the depth, and (b) the
+    project BatchNorm of every residual block has gamma in [0.1, 0.3] (trained residual branches contribute small
+    updates: gain < 1), and (c) the BatchNorms in front of a ReLU6 put most units into the activation's linear range
+    (beta in [0.8, 1.6], gamma in [0.4, 0.7]): a random BN + ReLU stack is CHAOTIC -- every rectification followed by a
+    mean removal grows a relative perturbation ~1.45x (measured on the calibrated net with beta ~ 0: 4e-3 behind Conv1 ->
+    8e-2 behind block 16) -- which no trained detector is.  Heads are tamed / calibrated exactly as in ``synthetic_weights``.  VGG16 has no BatchNorm and no
+    residuals: only the seed differs."""
+    import torch
+    from oracle import net_oracle as no
+    from oracle import torch_cpu_graph as tg
+    hp = hp or hyper_params(backbone)
+    key = ("trained", backbone, seed, target_frac, hp["total_labels"], hp["img_size"], calib_images)
+    if key in _WCACHE:
+        return _WCACHE[key]
+    rng = np.random.default_rng(seed)
+    w = {}
+    for name, shape in no.param_specs(backbone, hp):
+        var = name.rsplit("/", 1)[1]
+        if var == "kernel":
+            fan_in = shape[0] * shape[1] * shape[2]
+            w[name] = (rng.standard_normal(shape) * np.sqrt(2.0 / fan_in)).astype(np.float32)
+        elif var == "depthwise_kernel":
+            w[name] = (rng.standard_normal(shape) * np.sqrt(2.0 / 9.0)).astype(np.float32)
+        elif var == "gamma":
+            blk = name.split("_")[1] if name.startswith("block_") and "_project_BN" in name else None
+            if blk is not None and int(blk) in RESIDUAL_BLOCKS:
+                w[name] = rng.uniform(0.1, 0.3, shape).astype(np.float32)
+            elif "project_BN" in name:
+                w[name] = rng.uniform(0.8, 1.2, shape).astype(np.float32)
+            else:       # BatchNorm in front of a ReLU6: most units in the linear range (see the docstring)
+                w[name] = rng.uniform(0.4, 0.7, shape).astype(np.float32)
+        elif var == "beta":
+            if "project_BN" in name:
+                w[name] = rng.uniform(-0.2, 0.2, shape).astype(np.float32)
+            else:
+                w[name] = rng.uniform(0.8, 1.6, shape).astype(np.float32)
+        elif var == "moving_mean":
+            w[name] = np.zeros(shape, np.float32)
+        elif var == "moving_variance":
+            w[name] = np.ones(shape, np.float32)
+        elif var == "scale":
+            w[name] = np.full(shape, 20.0, np.float32)
+        else:  # bias
+            w[name] = rng.uniform(-0.05, 0.05, shape).astype(np.float32)
+    if any(n.endswith("moving_mean") for n in w):
+        T = {n: torch.from_numpy(v) for n, v in w.items()}
+        ids = {id(t): n for n, t in T.items()}
+        seen = {}
+
+        class CalibOps(tg.TorchOps):
+            @staticmethod
+            def batch_norm(x, gamma, beta, mean, var, eps=no.BN_EPS):
+                mu = x.mean(dim=(0, 2, 3))
+                va = ((x - mu.view(1, -1, 1, 1)) ** 2).mean(dim=(0, 2, 3))
+                seen[ids[id(mean)]] = mu.numpy().copy()
+                seen[ids[id(var)]] = np.maximum(va.numpy(), 1e-4).copy()
+                xh = (x - mu.view(1, -1, 1, 1)) * torch.rsqrt(va + eps).view(1, -1, 1, 1)
+                return xh * gamma.view(1, -1, 1, 1) + beta.view(1, -1, 1, 1)
+
+        with torch.no_grad():
+            no.forward(backbone, hp, T, images(calib_images, hp["img_size"], seed=1000 + seed), ops=CalibOps)
+        for n, v in seen.items():
+            w[n] = v.astype(np.float32)
+    _calibrate_heads(w, backbone, hp, target_frac, label_gain=0.35)
+    _WCACHE[key] = w
+    return w
+
+
+def _calibrate_heads(w, backbone, hp, target_frac, label_gain=0.5):
+    """Tame the head logits, then shift the background bias of the label heads (bisection on the oracle's logits of one
+    image) so that about ``target_frac`` of the anchors carry a non-background probability > 0.5."""
+    from oracle import net_oracle as no
     L = hp["total_labels"]
     for i in range(1, 7):
-        w["%d_conv_label_output/kernel" % i] *= np.float32(0.5)
+        w["%d_conv_label_output/kernel" % i] *= np.float32(label_gain)
         w["%d_conv_boxes_output/kernel" % i] *= np.float32(0.25)
     acts = {}
     no.forward(backbone, hp, w, images(1, hp["img_size"], seed=0), acts)
@@ -116,8 +201,6 @@ def synthetic_weights(backbone, hp=None, seed=1, target_frac=0.05):
     t = np.float32(0.5 * (lo + hi))
     for i in range(1, 7):
         w["%d_conv_label_output/bias" % i][0::L] += t
-    _WCACHE[key] = w
-    return w
 
 
 # --------------------------------------------------------------------------------------------

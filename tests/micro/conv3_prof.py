@@ -1,5 +1,5 @@
 """Cycle timeline of the split-bf16 conv loop (diagnostic; not a test):
-    tools/r4/build_c3prof.sh && python tests/micro/conv3_prof.py
+    tools/gpu/build_c3prof.sh && python tests/micro/conv3_prof.py
 The profiling build (-DSSD_C3_PROF, tests/micro/bin/libssd_hip_c3prof.so) accumulates, per wave of ONE workgroup, the core
 clocks between the loop's phase boundaries: [0] MFMA phase of the early group (waves 0-3), [1] split + LDS stores, [2] issue of
 the next tile's global loads, [3] MFMA phase of the late group (waves 4-7), [4] barrier wait; printed per K tile."""

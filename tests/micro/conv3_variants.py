@@ -1,5 +1,5 @@
 """Experimental variants of the split-bf16 conv tiles against the production kernel (diagnostic, not a test):
-    tools/r4/build_c3var.sh 1 2 ... && python tests/micro/conv3_variants.py 0 1 2 ...
+    tools/gpu/build_c3var.sh 1 2 ... && python tests/micro/conv3_variants.py 0 1 2 ...
 Each variant library (tests/micro/bin/libssd_hip_c3v<N>.so, -DSSD_C3_VARIANT=N in ssd_conv_mfma.h) runs the shapes
 below with a fixed (config, split-K); 0 = the production library."""
 import ctypes

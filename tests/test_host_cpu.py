@@ -405,3 +405,18 @@ def test_shipped_kernel_tables_were_measured_at_this_build():
         if not head or head[0].split("=", 1)[1] != want:
             stale.append(os.path.basename(t))
     assert not stale, "tables measured at another build than %s (re-run tools/make_tuning_tables.py): %s" % (want, stale[:4])
+
+
+def test_default_serving_setup_is_placed_before_the_runtime_starts():
+    """The measured serving setup (three in-order lanes on three hardware queues) is what a drop-in user gets without
+    setting anything: importing ``ssd_hip`` places GPU_MAX_HW_QUEUES=3 before torch / the HIP runtime start, unless the
+    process already chose a value or opts out; ``get_decoder_model`` then defaults to that many lanes in auto mode."""
+    pkg = os.path.join(REPO, "tf-ssd_amd")
+    code = ("import os, sys; sys.path.insert(0, %r); import ssd_hip; from models import decoder; "
+            "print(os.environ.get('GPU_MAX_HW_QUEUES'), decoder.default_lanes())" % pkg)
+    base = {k: v for k, v in os.environ.items() if k not in ("GPU_MAX_HW_QUEUES", "SSD_HIP_HW_QUEUES", "SSD_HIP_LANES")}
+    run = lambda env: subprocess.check_output([sys.executable, "-c", code], env=env, text=True).split()
+    assert run(base) == ["3", "3"]
+    assert run(dict(base, GPU_MAX_HW_QUEUES="8")) == ["8", "1"]             # the process chose: left alone
+    assert run(dict(base, GPU_MAX_HW_QUEUES="2")) == ["2", "2"]
+    assert run(dict(base, SSD_HIP_HW_QUEUES="runtime")) == ["None", "1"]    # opt-out: the runtime's own default

@@ -247,7 +247,7 @@ __device__ __forceinline__ void conv_mfma_body(const ConvParams& p, float* __res
     long long c3t0 = clock64();
 #endif
 #ifndef SSD_C3_VARIANT
-#define SSD_C3_VARIANT 0      // experiments (tools/r4/build_c3var.sh + tests/micro/conv3_variants.py); 0 = the production kernel
+#define SSD_C3_VARIANT 0      // experiments (tools/gpu/build_c3var.sh + tests/micro/conv3_variants.py); 0 = the production kernel
 #endif
 #ifdef SSD_C3_PROF            // diagnostics (tests/micro/conv3_prof.py): per-wave cycles of the loop's phases, dumped by one workgroup
 #define C3T(i) do { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); const long long t_ = clock64(); c3tp[i] += t_ - c3t0; c3t0 = t_; } while (0)

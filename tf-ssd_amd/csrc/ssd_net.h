@@ -109,6 +109,7 @@ struct ssd_net {
     void* nms_ws = nullptr;
     size_t nms_ws_bytes = 0;
     int nms_ws_batch = 0;           // the batch the workspace was carved (and its candidate counters zeroed) for
+    int nms_ws_total = 0;           // ... and the max_total it was carved for
     int scratch_batch = 0;          // batch capacity deltas/probs were allocated for
     // optional per-layer hipEvent timing of forward()/predict() (bench.py roofline leg)
     std::map<std::string, std::pair<std::string, int>> preset;   // layer -> (config name, split_k)

@@ -364,7 +364,8 @@ static FusedBlockParams fused_params(const ssd_net& net, const Layer& f, int B) 
         p.wp3 = conv_split_planes(f.fz_wp, lp.Cin, lp.Cout);
         p.groups = net.img_slabs ? image_block_groups(p, B * net.lanes_hint) : 1;
         p.slabs = net.img_slabs;
-        p.tickets = net.image_ticket ? net.img_tickets : nullptr;
+        // (the in-launch ticketed combine exists for the fp32-MFMA form only: a no-op for the bf16 / split-bf16 forms)
+        p.tickets = net.image_ticket && !p.bf16 ? net.img_tickets : nullptr;
         if (!p.bf16 && f.img_choice == 2) { p.bf16 = 3; p.tickets = nullptr; }    // the split-bf16 form of the image kernel (fp32 results)
     }
     return p;
@@ -1317,8 +1318,12 @@ int ssd_net_predict(ssd_net* net, const float* image_dev, int B, const float* pr
         SSD_HIP(hipMalloc((void**)&net->probs, (size_t)net->max_batch * N * L * sizeof(float)));
         net->scratch_batch = net->max_batch;
     }
-    const size_t need = ssd_decode_nms_workspace_bytes(net->max_batch, N, L, max_total);
-    if (need > net->nms_ws_bytes) {
+    // the fused decoder carves the workspace for nms_ws_batch images whatever B a call runs: a re-finalize with another
+    // max_batch, or a call with a larger max_total, re-carves -- and re-zeroes -- it (never a layout for one batch over
+    // counters left by another)
+    const int ws_batch = std::max(net->max_batch, net->nms_ws_batch);
+    const size_t need = ssd_decode_nms_workspace_bytes(ws_batch, N, L, max_total);
+    if (need > net->nms_ws_bytes || ws_batch != net->nms_ws_batch || max_total != net->nms_ws_total) {
         (void)hipDeviceSynchronize();
         net->drop_graphs();
         if (net->nms_ws) (void)hipFree(net->nms_ws);
@@ -1327,7 +1332,8 @@ int ssd_net_predict(ssd_net* net, const float* image_dev, int B, const float* pr
         SSD_HIP(hipMalloc(&net->nms_ws, need));
         SSD_HIP(hipMemset(net->nms_ws, 0, need));      // candidate counters start at zero and are re-zeroed by every call (nms_class_kernel)
         net->nms_ws_bytes = need;
-        net->nms_ws_batch = net->max_batch;
+        net->nms_ws_batch = ws_batch;
+        net->nms_ws_total = max_total;
     }
     hipStream_t st = (hipStream_t)stream;
     SSD_CHECK_ARG(var != nullptr, "ssd_net_predict: variances pointer is NULL");
@@ -1351,6 +1357,12 @@ int ssd_net_predict(ssd_net* net, const float* image_dev, int B, const float* pr
                               score_thr, boxes_dev, labels_dev, scores_dev, valid_dev, nullptr, net->nms_ws,
                               net->nms_ws_bytes, (void*)st);
     });
+    if (rc && fused_sm && net->nms_ws) {
+        // a step that failed between the compaction and the per-class kernel leaves candidate counters behind: the next
+        // call must not read them as keys
+        (void)hipDeviceSynchronize();
+        (void)hipMemset(net->nms_ws, 0, net->nms_ws_bytes);
+    }
     if (!rc && net->timing && !net->timing_events.empty())
         (void)hipEventRecord(net->timing_events.back().back(), st);
     return rc;

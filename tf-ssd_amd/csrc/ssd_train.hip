@@ -17,6 +17,7 @@
 #include <cmath>
 #include <cstring>
 #include <map>
+#include <mutex>
 
 #include "ssd_bf16x3.h"
 #include "ssd_net.h"
@@ -1054,20 +1055,25 @@ static thread_local double g_step_flops[3] = {0, 0, 0};
 // bit-exactness contract; the inference path keeps its shipped tables).  SSD_HIP_TRAIN_AUTOTUNE=0: the cost model
 // (conv_pick_config: deterministic); =2 also prints what was found.
 struct TrainPickKey {
-    long M; int K, Cout, kh, kw, stride, dil, H, W, Cin, flags;
+    long M, ops, obs; int K, Cout, kh, kw, stride, dil, H, W, Cin, flags, pad_t, pad_l;
     bool operator<(const TrainPickKey& o) const { return memcmp(this, &o, sizeof(*this)) < 0; }
 };
 static std::map<TrainPickKey, int>& train_picks() { static std::map<TrainPickKey, int> m; return m; }
+static std::mutex& train_picks_mutex() { static std::mutex m; return m; }      // nets of several host threads share the memo
 
 static int pick_measured(const ConvParams& p, hipStream_t st, int model_cfg, int verbose) {
     TrainPickKey k{};
     memset(&k, 0, sizeof(k));
     k.M = p.M; k.K = p.K; k.Cout = p.Cout; k.kh = p.kh; k.kw = p.kw; k.stride = p.stride; k.dil = p.dil; k.H = p.H; k.W = p.W;
-    k.Cin = p.Cin;
+    k.Cin = p.Cin; k.pad_t = p.pad_t; k.pad_l = p.pad_l; k.ops = p.out_pixel_stride; k.obs = p.out_batch_stride;
     k.flags = (p.residual ? 1 : 0) | (p.n_split ? 2 : 0) | (p.scale ? 4 : 0) | (p.shift ? 8 : 0) | (p.act << 4) | (p.bf16 << 8) |
               (p.vec_store << 9);
-    auto it = train_picks().find(k);
-    if (it != train_picks().end()) return it->second;
+    {
+        std::lock_guard<std::mutex> lock(train_picks_mutex());
+        auto it = train_picks().find(k);
+        // (a memoised pick is re-validated against THESE parameters: alignment of the pointers is not part of the key)
+        if (it != train_picks().end()) return conv_config_valid(it->second, p) ? it->second : model_cfg;
+    }
     float* scratch = nullptr;
     const size_t out_floats = (size_t)p.M * (size_t)(p.out_pixel_stride > p.Cout ? p.out_pixel_stride : p.Cout) + 4096;
     if (hipMalloc((void**)&scratch, out_floats * sizeof(float)) != hipSuccess) { (void)hipGetLastError(); return model_cfg; }
@@ -1103,7 +1109,10 @@ static int pick_measured(const ConvParams& p, hipStream_t st, int model_cfg, int
     if (verbose)
         fprintf(stderr, "[ssd train tune] M=%ld K=%d N=%d k%dx%d s%d: model %s %.1f us -> %s %.1f us\n", p.M, p.K, p.Cout, p.kh, p.kw,
                 p.stride, conv_config_name(model_cfg), model_ms * 1000.f / 3, conv_config_name(best), best_ms * 1000.f / 3);
-    train_picks()[k] = best;
+    {
+        std::lock_guard<std::mutex> lock(train_picks_mutex());
+        train_picks()[k] = best;
+    }
     return best;
 }
 

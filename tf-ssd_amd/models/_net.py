@@ -11,7 +11,9 @@ import torch
 import ssd_hip as _h
 
 # options that change which kernel configurations finalize may choose (the memo is per option set)
-_TABLE_OPTIONS = ("use_wino",)
+_TABLE_OPTIONS = ("use_wino", "image_split", "conv_dma")
+# options that make the native net drop `finalized` (ssd_net_set_option): the Python handle must re-finalize too
+_REFINALIZE_OPTIONS = ("precision", "image_split", "use_wino", "conv_dma")
 _STALE_WARNED = set()
 
 
@@ -474,8 +476,18 @@ class SSDModel(object):
         return lm + cm + self.regularization_loss(), lm, cm
 
     def set_option(self, name, value):
-        _h.check(_h.lib().ssd_net_set_option(self._net, name.encode(), int(value)), "set_option")
-        self._options[name] = int(value)
+        value = int(value)
+        if name == "precision" and value not in (0, 1):
+            raise ValueError("option precision must be 0 (fp32) or 1 (bf16), got %r" % (value,))
+        _h.check(_h.lib().ssd_net_set_option(self._net, name.encode(), value), "set_option")
+        self._options[name] = value
+        if name == "precision":
+            # the table key, the tune-cache file and clone() all follow self.precision: a net switched after
+            # construction must not memoise its bf16 table under the fp32 key
+            self.precision = "bf16" if value else "fp32"
+            self._train_batch = 0
+        if name in _REFINALIZE_OPTIONS:
+            self._finalized_for = 0
 
     def set_timing(self, enabled):
         _h.check(_h.lib().ssd_net_set_timing(self._net, int(enabled)), "set_timing")

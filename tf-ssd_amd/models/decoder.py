@@ -75,9 +75,13 @@ class DecoderModel(object):
     """What ``get_decoder_model`` returns: ``Model(inputs=base.input, outputs=[bboxes,
     classes, scores])`` (reference models/decoder.py:68-69), used through ``predict``."""
 
-    def __init__(self, base_model, decoder, lanes=1):
+    def __init__(self, base_model, decoder, lanes=1, auto_lanes=False):
         self.base_model = base_model
         self.decoder = decoder
+        # auto_lanes (``get_decoder_model`` without ``lanes`` / SSD_HIP_LANES): ``predict`` keeps ``lanes`` batches in
+        # flight only when it has enough batches to fill them (>= 2 per lane); shorter calls, ``__call__`` and
+        # ``predict_on_batch`` run one step at a time on the base model (bitwise the classic path)
+        self.auto_lanes = bool(auto_lanes)
         # lanes > 1: ``submit`` / ``predict`` keep that many batches in flight, each on its own replica of
         # the net (own arena / scratch / streams, same weights) and its own stream, launched directly (no
         # graph replay): the latency-bound end of step n -- small heads, softmax, decode/NMS -- and its big
@@ -270,8 +274,11 @@ class DecoderModel(object):
             # per-lane device buffer: the copy of step n + lanes into it is ordered behind step n's kernels on the same stream
             buf = self._lane_inputs.get((i, x.dtype))
             if buf is None or buf.shape[0] < x.shape[0] or buf.shape[1:] != x.shape[1:]:
-                buf = torch.empty((max(x.shape[0], getattr(self.base_model, "_max_batch", 0) or 0),) + tuple(x.shape[1:]),
-                                  dtype=x.dtype, device=_h.device())
+                if buf is not None:
+                    buf.record_stream(st)          # the lane may still be reading the block that goes back to the pool
+                with torch.cuda.stream(st):        # allocated ON the lane's stream: the block's first writer is that stream
+                    buf = torch.empty((max(x.shape[0], getattr(self.base_model, "_max_batch", 0) or 0),) + tuple(x.shape[1:]),
+                                      dtype=x.dtype, device=_h.device())
                 self._lane_inputs[(i, x.dtype)] = buf
             with torch.cuda.stream(st):
                 xd = buf[:x.shape[0]]
@@ -280,6 +287,8 @@ class DecoderModel(object):
                     S = int(self.base_model.img_size)
                     fb = self._lane_inputs.get((i, "f32"))
                     if fb is None or fb.shape[0] < x.shape[0] or fb.shape[1] != S:
+                        if fb is not None:
+                            fb.record_stream(st)
                         fb = torch.empty((max(x.shape[0], getattr(self.base_model, "_max_batch", 0) or 0), S, S, 3),
                                          dtype=torch.float32, device=_h.device())
                         self._lane_inputs[(i, "f32")] = fb
@@ -352,11 +361,20 @@ class DecoderModel(object):
         chunks) or an iterable of batches (an image array, or a tuple whose first element
         is the image batch, like the reference's padded-batch dataset).  Returns three
         NumPy arrays concatenated over the batches (reference predictor.py:52)."""
+        n_batches = None
         if isinstance(x, (np.ndarray, torch.Tensor)):
             n = x.shape[0]
+            n_batches = (n + batch_size - 1) // batch_size
             batches = (x[i:i + batch_size] for i in range(0, n, batch_size))
         else:
+            try:
+                n_batches = len(x)
+            except TypeError:
+                n_batches = None                     # a generator / dataset of unknown length: assume a long run
             batches = iter(x)
+        if steps is not None:
+            n_batches = steps if n_batches is None else min(n_batches, steps)
+        use_lanes = self.lanes > 1 and not (self.auto_lanes and n_batches is not None and n_batches < 2 * self.lanes)
         outs = ([], [], [])
         done = 0
         pending = []
@@ -364,7 +382,7 @@ class DecoderModel(object):
             if steps is not None and done >= steps:
                 break
             imgs = batch[0] if isinstance(batch, (tuple, list)) else batch
-            if self.lanes > 1:
+            if use_lanes:
                 pending.append(self.submit(imgs))        # device tensors; copied out after the last batch
             else:
                 res = self.predict_on_batch(imgs)
@@ -387,11 +405,28 @@ class DecoderModel(object):
         return tuple(np.concatenate(a, 0) for a in outs)
 
 
+def default_lanes():
+    """Batches ``predict`` keeps in flight when the caller does not say: as many as the HIP runtime has hardware
+    queues when that number was limited to 2 or 3 (GPU_MAX_HW_QUEUES; ``ssd_hip`` sets 3 before the runtime starts
+    unless the process chose otherwise) -- every lane then owns a queue (section 5 of DESIGN.md: 3 lanes / 3 queues
+    50 k images/sec against 41 k one step at a time at B=64) -- else 1."""
+    import os
+    q = os.environ.get("GPU_MAX_HW_QUEUES", "")
+    return int(q) if q.isdigit() and 1 < int(q) < 4 else 1
+
+
 def get_decoder_model(base_model, prior_boxes, hyper_params, lanes=None):
-    """reference models/decoder.py:57-69.  ``lanes`` (default: env SSD_HIP_LANES or 1) batches in flight
-    for ``predict`` / ``submit`` (see DecoderModel)."""
+    """reference models/decoder.py:57-69.  ``lanes``: batches in flight for ``predict`` / ``submit`` (see
+    DecoderModel).  Default: env SSD_HIP_LANES, else ``default_lanes()`` in AUTO mode -- ``predict`` uses the lanes
+    when it has at least two batches per lane (a short check on the first such call falls back to one lane where
+    lanes do not pay), everything else stays on the one-step-at-a-time path."""
     import os
     decoder = SSDDecoder(prior_boxes, hyper_params["variances"])
+    auto = False
     if lanes is None:
-        lanes = int(os.environ.get("SSD_HIP_LANES", "1"))
-    return DecoderModel(base_model, decoder, lanes=lanes)
+        env = os.environ.get("SSD_HIP_LANES")
+        if env is not None:
+            lanes = int(env)
+        else:
+            lanes, auto = default_lanes(), True
+    return DecoderModel(base_model, decoder, lanes=lanes, auto_lanes=auto)

@@ -6,9 +6,31 @@ device is visible, every compute entry point raises.
 """
 import ctypes
 import os
+import sys
 
-import numpy as np
-import torch
+
+def _default_hw_queues():
+    """The measured serving setup needs the HIP runtime limited to as many hardware queues as there
+    are lanes: three in-order lanes on three queues.  The runtime reads GPU_MAX_HW_QUEUES when it starts, so the default
+    is placed HERE, before this module imports torch -- unless the process already chose (the variable is set), opts out
+    (SSD_HIP_HW_QUEUES=runtime keeps the runtime's own default) or the runtime is already up (then it is too late and
+    ``models.decoder.default_lanes()`` answers 1)."""
+    want = os.environ.get("SSD_HIP_HW_QUEUES", "3")
+    if "GPU_MAX_HW_QUEUES" in os.environ or want in ("runtime", "0", ""):
+        return
+    t = sys.modules.get("torch")
+    try:
+        if t is not None and t.cuda.is_initialized():
+            return
+    except Exception:
+        return
+    os.environ["GPU_MAX_HW_QUEUES"] = want
+
+
+_default_hw_queues()
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SSD_HIP_LIBRARY") or os.path.join(_HERE, "libssd_hip.so")   # override: diagnostic builds

@@ -1,6 +1,6 @@
 #!/bin/bash
 # Experimental builds of the split-bf16 conv tiles: tests/micro/bin/libssd_hip_c3v<N>.so with -DSSD_C3_VARIANT=N
-# (tests/micro/bin/ is git-ignored but travels with gpurun).  usage: tools/r4/build_c3var.sh 1 2 ...
+# (tests/micro/bin/ is git-ignored but travels with gpurun).  usage: tools/gpu/build_c3var.sh 1 2 ...
 set -e
 cd "$(dirname "$0")/../../tf-ssd_amd/csrc"
 bash build.sh
