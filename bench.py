@@ -51,9 +51,9 @@ PEAK_SPLIT_BF16_TFLOPS = PEAK_BF16_MFMA_TFLOPS / 6.0
 def matrix_peak(config):
     """Matrix-core peak of a conv kernel family (by config name): fp32 MFMA tiles, split-bf16 tiles (fp32 results through
     six bf16 products: fp32-equivalent = dense bf16 / 6), bf16 tiles (--dtype bf16: one product, the dense bf16 peak)."""
-    if config.startswith("bf16_"):
+    if config.startswith(("bf16_", "dmab_")):
         return PEAK_BF16_MFMA_TFLOPS
-    return PEAK_SPLIT_BF16_TFLOPS if config.startswith("mfma3_") else PEAK_FP32_MFMA_TFLOPS
+    return PEAK_SPLIT_BF16_TFLOPS if config.startswith(("mfma3_", "dma3_")) else PEAK_FP32_MFMA_TFLOPS
 
 
 def fused_peak(config):
@@ -311,7 +311,7 @@ def main():
     info, nfw = model.read_timing(B)
     model.set_timing(False)
     # the dense-conv family on the fp32 matrix cores: implicit-GEMM tiles and Winograd F(2x2,3x3) tiles
-    mfma = [r for r in info if r["kind"] == "conv" and r["config"].startswith(("mfma_", "mfma3_", "bf16_", "wino_", "skinny_")) and r["flops"] > 0]
+    mfma = [r for r in info if r["kind"] == "conv" and r["config"].startswith(("mfma_", "mfma3_", "bf16_", "wino_", "skinny_", "dma3_", "dmab_")) and r["flops"] > 0]
     mfma_ms = sum(r["ms"] for r in mfma)
     mfma_flops = sum(r["flops"] for r in mfma)
     mfma_exec = sum(r["executed_flops"] for r in mfma)
@@ -326,8 +326,12 @@ def main():
             k = "conv_winograd"
         elif k == "conv" and r["config"].startswith("mfma3_"):
             k = "conv_split_bf16"
+        elif k == "conv" and r["config"].startswith("dma3_"):
+            k = "conv_split_bf16_ldsdma"
         elif k == "conv" and r["config"].startswith("bf16_"):
             k = "conv_bf16"
+        elif k == "conv" and r["config"].startswith("dmab_"):
+            k = "conv_bf16_ldsdma"
         elif k == "conv" and not r["config"].startswith(("mfma_", "skinny_")):
             k = "conv_direct"
         kinds[k] = kinds.get(k, 0.0) + r["ms"]
@@ -338,7 +342,7 @@ def main():
     ideal_ms = sum(r["executed_flops"] / (matrix_peak(r["config"]) * 1e12) * 1e3 for r in mfma)
     frac = ideal_ms / mfma_ms if mfma_ms > 0 else 0.0
     peak_eff = executed / frac if frac > 0 else PEAK_FP32_MFMA_TFLOPS
-    split = [r for r in mfma if r["config"].startswith("mfma3_")]
+    split = [r for r in mfma if r["config"].startswith(("mfma3_", "dma3_"))]
     # the single most expensive launch of the family: what `rocprofv3 --kernel-trace --stats` of
     # `bench.py --no-overlap --no-other-leg` lists as that kernel's average duration (profiles/)
     dom = max(mfma, key=lambda r: r["ms"]) if mfma else None
@@ -438,7 +442,8 @@ def main():
                      "frac": frac, "frac_kind": "sum(executed FLOPs / peak of the layer's matrix instruction) / measured time",
                      "peak_detail": {"fp32_mfma": PEAK_FP32_MFMA_TFLOPS, "bf16_mfma_dense": PEAK_BF16_MFMA_TFLOPS,
                                      "split_bf16_fp32_equivalent": PEAK_SPLIT_BF16_TFLOPS,
-                                     "bf16_layers": len([r for r in mfma if r["config"].startswith("bf16_")]),
+                                     "bf16_layers": len([r for r in mfma if r["config"].startswith(("bf16_", "dmab_"))]),
+                                     "lds_dma_layers": len([r for r in mfma if r["config"].startswith(("dma3_", "dmab_"))]),
                                      "split_bf16_layers": len(split), "split_bf16_ms_per_step": sum(r["ms"] for r in split),
                                      "split_bf16_executed_gflop_per_step": sum(r["executed_flops"] for r in split) / 1e9},
                      "achieved_algorithmic": achieved, "frac_algorithmic_vs_fp32_mfma_peak": achieved / PEAK_FP32_MFMA_TFLOPS,

@@ -192,6 +192,20 @@ int ssd_conv2d_ex(const ssd_conv_desc* d, const float* in_dev, const float* pack
                   float* out_dev, long out_batch_stride, long out_pixel_stride, int config,
                   int split_k, float* splitk_ws_dev, void* stream);
 
+/* The same op on the LDS-DMA tiles ("dma3_*" / "dmab_*" configs, csrc/ssd_convdma.hip): the INPUT is handed over as
+ * bf16 planes [planes][n] (planes = 3: the exact split x = h + m + l of the fp32 activation, fp32 results as above;
+ * planes = 1: its bf16 rounding -- the bf16 mode's storage format), `in_plane_stride` ELEMENTS between planes; both
+ * operands then reach LDS by `buffer_load ... lds` without passing through registers.  ssd_split_planes writes such
+ * planes from an fp32 tensor (n % 4 == 0), ssd_join_planes restores fp32 (exactly, for planes = 3); the conv can write
+ * its own output as planes too (out_planes_dev != NULL: dense outputs with Cout % 4 == 0) for the next layer. */
+int ssd_split_planes(const float* x_dev, long n, int planes, void* planes_dev, long plane_stride, void* stream);
+int ssd_join_planes(const void* planes_dev, long n, int planes, long plane_stride, float* x_dev, void* stream);
+int ssd_conv2d_planes(const ssd_conv_desc* d, const void* in_planes_dev, int planes, long in_plane_stride,
+                      const float* packed_w_dev, const float* scale_dev, const float* shift_dev,
+                      const float* residual_dev, float* out_dev, long out_batch_stride, long out_pixel_stride,
+                      void* out_planes_dev, long out_plane_stride, int config, int split_k,
+                      float* splitk_ws_dev, void* stream);
+
 /* Winograd F(2x2,3x3) variant of the same op for 3x3 stride-1 dilation-1 convs with Cin % 16 == 0
  * (the SSD head convs, models/header.py:60-61, and VGG16's 3x3 backbone, models/ssd_vgg16.py:52-72):
  * 2.25x fewer multiplications on the same fp32 MFMA, fused input / output transforms.  Weights are

@@ -32,6 +32,16 @@ struct ConvParams {
     float* partial;
     const float* wino_w;   // Winograd F(2x2,3x3) weights U [16][Npad][Cin] (ssd_wino.hip) or nullptr
     int bf16;              // the net's precision-1 mode: the cost model (conv_pick_config) may take the bf16 tiles
+    // LDS-DMA tiles (csrc/ssd_convdma.hip): the INPUT as bf16 planes [np][B*H*W*Cin] (np = 3: exact split h, m, l of the
+    // fp32 activation; np = 1: its bf16 rounding), `xp_plane` elements between planes; nullptr = not available
+    const short* xp;
+    long xp_plane;
+    int xp_np;
+    // ... and the OUTPUT also written as planes by the epilogue (dense [M][Cout] outputs only; Cout % 4 == 0) for the
+    // LDS-DMA tiles of this layer's consumers; nullptr = fp32 only
+    short* op;
+    long op_plane;
+    int op_np;
 };
 // may a net of this precision (0 fp32, 1 bf16) choose config `cfg`?  fp32 nets never take the bf16 (one-product) tiles;
 // bf16 nets take them instead of the split-bf16 / Winograd tiles (the fp32-MFMA and skinny tiles serve the small tail layers
@@ -162,6 +172,20 @@ int mfma3_k_tiles(const ConvParams& p);
 void mfma3_tile(int i, int* BM, int* BN);
 int mfma3_launch(const ConvParams& p, int i, hipStream_t st, bool bf16 = false);
 const char* bf16_config_name(int i);     // bf16 (one-product) form of split-bf16 tile i; config ids behind the mfma3 ones
+
+// LDS-DMA tiles over pre-split bf16 activation planes (csrc/ssd_convdma.hip); config ids behind the bf16 ones:
+// "dma3_*" (np = 3, fp32 nets) then "dmab_*" (np = 1, the bf16 mode)
+int dma_num_configs();
+const char* dma_config_name(int i, int np);
+bool dma_config_valid(int i, int np, const ConvParams& p);
+long dma_grid_blocks(int i, const ConvParams& p);
+int dma_k_tiles(int np, const ConvParams& p);
+void dma_tile(int i, int* BM, int* BN);
+int dma_launch(const ConvParams& p, int i, int np, hipStream_t st);
+int launch_split_planes(const float* x, long n, int np, short* planes, long plane, hipStream_t st);
+int launch_join_planes(const short* planes, long n, int np, long plane, float* x, hipStream_t st);
+bool conv_config_is_dma(int cfg);          // either family
+bool conv_config_writes_planes(int cfg);   // the family's epilogue (conv_epilogue / splitk_reduce_kernel) honours ConvParams::op
 
 int launch_dwconv3x3(const float* in, int B, int H, int W, int C, int stride, int pad_t, int pad_l,
                      int Ho, int Wo, const float* w, const float* scale, const float* shift, int act,

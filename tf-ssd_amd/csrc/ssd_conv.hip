@@ -66,7 +66,10 @@ __global__ void splitk_reduce_kernel(const ConvParams p) {
             else
                 p.out[(long)b * p.out_batch_stride + pix * p.out_pixel_stride + n] = r;
             if (++n == p.Cout) { n = 0; ++m; }
+            t[j] = r;
         }
+        // (dense outputs with Cout % 4 == 0 only: the four elements lie in one row)
+        if (V == 4 && p.op) store_planes4(p.op, p.op_plane, p.op_np, g * V, f32x4{t[0], t[1], t[2], t[3]});
     }
 }
 
@@ -285,17 +288,28 @@ static int skinny_cfg0() { return kNumMfmaCfgs + wino_num_configs(); }
 static int mfma3_cfg0() { return kNumMfmaCfgs + wino_num_configs() + skinny_num_configs(); }
 // then the same tiles as bf16 (one-product) kernels: only chosen when asked for by name / by the net's precision-1 mode
 static int bf16_cfg0() { return kNumMfmaCfgs + wino_num_configs() + skinny_num_configs() + mfma3_num_configs(); }
-static int direct_cfg() { return kNumMfmaCfgs + wino_num_configs() + skinny_num_configs() + 2 * mfma3_num_configs(); }
+// then the LDS-DMA tiles over pre-split activation planes (csrc/ssd_convdma.hip): "dma3_*" (fp32 nets), "dmab_*" (bf16 mode)
+static int dma3_cfg0() { return kNumMfmaCfgs + wino_num_configs() + skinny_num_configs() + 2 * mfma3_num_configs(); }
+static int dmab_cfg0() { return dma3_cfg0() + dma_num_configs(); }
+static int direct_cfg() { return dma3_cfg0() + 2 * dma_num_configs(); }
 #define kSkinnyCfg0 skinny_cfg0()
 #define kMfma3Cfg0 mfma3_cfg0()
 #define kBf16Cfg0 bf16_cfg0()
+#define kDma3Cfg0 dma3_cfg0()
+#define kDmabCfg0 dmab_cfg0()
 #define kDirectCfg direct_cfg()
+bool conv_config_is_dma(int cfg) { return cfg >= kDma3Cfg0 && cfg < kDirectCfg; }
+bool conv_config_writes_planes(int cfg) {
+    return (cfg >= 0 && cfg < kNumMfmaCfgs) || (cfg >= kMfma3Cfg0 && cfg < kDirectCfg);      // fp32-MFMA, split-bf16, bf16 and LDS-DMA tiles
+}
 
 int conv_num_mfma_configs() { return kNumMfmaCfgs; }
 int conv_num_configs() { return kDirectCfg + 1; }
 const char* conv_config_name(int cfg) {
     if (cfg == kDirectCfg) return "direct_valu";
-    if (cfg >= kBf16Cfg0 && cfg < kDirectCfg) return bf16_config_name(cfg - kBf16Cfg0);
+    if (cfg >= kDmabCfg0 && cfg < kDirectCfg) return dma_config_name(cfg - kDmabCfg0, 1);
+    if (cfg >= kDma3Cfg0 && cfg < kDmabCfg0) return dma_config_name(cfg - kDma3Cfg0, 3);
+    if (cfg >= kBf16Cfg0 && cfg < kDma3Cfg0) return bf16_config_name(cfg - kBf16Cfg0);
     if (cfg >= kMfma3Cfg0 && cfg < kBf16Cfg0) return mfma3_config_name(cfg - kMfma3Cfg0);
     if (cfg >= kSkinnyCfg0 && cfg < kMfma3Cfg0) return skinny_config_name(cfg - kSkinnyCfg0);
     if (cfg >= kNumMfmaCfgs && cfg < kSkinnyCfg0) return wino_config_name(cfg - kNumMfmaCfgs);
@@ -304,9 +318,10 @@ const char* conv_config_name(int cfg) {
 }
 
 bool conv_config_allowed(int cfg, int precision) {
-    const bool bf16 = cfg >= kBf16Cfg0 && cfg < kDirectCfg;
+    const bool bf16 = (cfg >= kBf16Cfg0 && cfg < kDma3Cfg0) || (cfg >= kDmabCfg0 && cfg < kDirectCfg);
     if (!precision) return !bf16;
-    const bool split = cfg >= kMfma3Cfg0 && cfg < kBf16Cfg0, wino = cfg >= kNumMfmaCfgs && cfg < kSkinnyCfg0;
+    const bool split = (cfg >= kMfma3Cfg0 && cfg < kBf16Cfg0) || (cfg >= kDma3Cfg0 && cfg < kDmabCfg0);
+    const bool wino = cfg >= kNumMfmaCfgs && cfg < kSkinnyCfg0;
     return !split && !wino;
 }
 
@@ -316,7 +331,9 @@ static bool is_gemm1x1(const ConvParams& p) {
 
 bool conv_config_valid(int cfg, const ConvParams& p) {
     if (cfg == kDirectCfg) return (size_t)p.K * ((p.Cout + 3) & ~3) * 4 <= 64 * 1024;
-    if (cfg >= kBf16Cfg0 && cfg < kDirectCfg) return mfma3_config_valid(cfg - kBf16Cfg0, p);
+    if (cfg >= kDmabCfg0 && cfg < kDirectCfg) return dma_config_valid(cfg - kDmabCfg0, 1, p);
+    if (cfg >= kDma3Cfg0 && cfg < kDmabCfg0) return dma_config_valid(cfg - kDma3Cfg0, 3, p);
+    if (cfg >= kBf16Cfg0 && cfg < kDma3Cfg0) return mfma3_config_valid(cfg - kBf16Cfg0, p);
     if (cfg >= kMfma3Cfg0 && cfg < kBf16Cfg0) return mfma3_config_valid(cfg - kMfma3Cfg0, p);
     if (cfg >= kSkinnyCfg0 && cfg < kMfma3Cfg0) return skinny_config_valid(cfg - kSkinnyCfg0, p);
     if (cfg >= kNumMfmaCfgs && cfg < kSkinnyCfg0) return wino_config_valid(cfg - kNumMfmaCfgs, p);
@@ -370,7 +387,9 @@ int conv_pick_config(const ConvParams& p) {
 }
 
 long conv_grid_blocks(int cfg, const ConvParams& p) {
-    if (cfg >= kBf16Cfg0 && cfg < kDirectCfg) return mfma3_grid_blocks(cfg - kBf16Cfg0, p);
+    if (cfg >= kDmabCfg0 && cfg < kDirectCfg) return dma_grid_blocks(cfg - kDmabCfg0, p);
+    if (cfg >= kDma3Cfg0 && cfg < kDmabCfg0) return dma_grid_blocks(cfg - kDma3Cfg0, p);
+    if (cfg >= kBf16Cfg0 && cfg < kDma3Cfg0) return mfma3_grid_blocks(cfg - kBf16Cfg0, p);
     if (cfg >= kMfma3Cfg0 && cfg < kBf16Cfg0) return mfma3_grid_blocks(cfg - kMfma3Cfg0, p);
     if (cfg >= kSkinnyCfg0 && cfg < kMfma3Cfg0) return skinny_grid_blocks(cfg - kSkinnyCfg0, p);
     if (cfg >= kNumMfmaCfgs && cfg < kSkinnyCfg0) return wino_grid_blocks(cfg - kNumMfmaCfgs, p);
@@ -379,7 +398,8 @@ long conv_grid_blocks(int cfg, const ConvParams& p) {
     return ((p.M + g.BM - 1) / g.BM) * ((p.Cout + g.BN - 1) / g.BN);
 }
 int conv_k_tiles(int cfg, const ConvParams& p) {
-    if (cfg >= kMfma3Cfg0 && cfg < kDirectCfg) return mfma3_k_tiles(p);      // (split-bf16 and bf16 tiles)
+    if (cfg >= kDma3Cfg0 && cfg < kDirectCfg) return dma_k_tiles(cfg >= kDmabCfg0 ? 1 : 3, p);
+    if (cfg >= kMfma3Cfg0 && cfg < kDma3Cfg0) return mfma3_k_tiles(p);      // (split-bf16 and bf16 tiles)
     if (cfg >= kSkinnyCfg0 && cfg < kMfma3Cfg0) return p.K / 16;
     if (cfg >= kNumMfmaCfgs && cfg < kSkinnyCfg0) return wino_k_tiles(p);
     if (cfg < 0 || cfg >= kNumMfmaCfgs) return 0;
@@ -397,7 +417,13 @@ int conv_launch(const ConvParams& p, int cfg, hipStream_t st) {
                   p.Cin, p.kh, p.kw, p.stride);
         return SSD_E_UNSUPPORTED;
     }
-    if (cfg >= kMfma3Cfg0 && cfg < kDirectCfg) {
+    if (cfg >= kDma3Cfg0 && cfg < kDirectCfg) {
+        const bool b1 = cfg >= kDmabCfg0;
+        const int rc = dma_launch(p, cfg - (b1 ? kDmabCfg0 : kDma3Cfg0), b1 ? 1 : 3, st);
+        if (rc || p.split_k <= 1) return rc;
+        return launch_splitk_reduce(p, st);
+    }
+    if (cfg >= kMfma3Cfg0 && cfg < kDma3Cfg0) {
         const bool bf16 = cfg >= kBf16Cfg0;
         const int rc = mfma3_launch(p, cfg - (bf16 ? kBf16Cfg0 : kMfma3Cfg0), st, bf16);
         if (rc || p.split_k <= 1) return rc;
@@ -550,6 +576,54 @@ int ssd_conv2d_ex(const ssd_conv_desc* d, const float* in_dev, const float* pack
     SSD_UNSUPPORTED_IF(cfg < 0, "conv2d: no kernel for Cin=%d Cout=%d k=%dx%d", p.Cin, p.Cout, p.kh, p.kw);
     if (cfg == conv_num_configs() - 1) p.split_k = 1;
     return conv_launch(p, cfg, (hipStream_t)stream);
+}
+
+int ssd_split_planes(const float* x_dev, long n, int planes, void* planes_dev, long plane_stride, void* stream) {
+    SSD_CHECK_ARG(x_dev && planes_dev && n >= 0, "ssd_split_planes: bad arguments");
+    SSD_CHECK_ARG(plane_stride >= n && plane_stride % 8 == 0, "ssd_split_planes: plane_stride %ld must be >= n and a multiple of 8", plane_stride);
+    SSD_CHECK_ARG((((uintptr_t)x_dev | (uintptr_t)planes_dev) & 15) == 0, "ssd_split_planes: pointers must be 16-byte aligned");
+    return launch_split_planes(x_dev, n, planes, static_cast<short*>(planes_dev), plane_stride, (hipStream_t)stream);
+}
+
+int ssd_join_planes(const void* planes_dev, long n, int planes, long plane_stride, float* x_dev, void* stream) {
+    SSD_CHECK_ARG(x_dev && planes_dev && n >= 0 && (planes == 1 || planes == 3) && plane_stride >= n, "ssd_join_planes: bad arguments");
+    return launch_join_planes(static_cast<const short*>(planes_dev), n, planes, plane_stride, x_dev, (hipStream_t)stream);
+}
+
+int ssd_conv2d_planes(const ssd_conv_desc* d, const void* in_planes_dev, int planes, long in_plane_stride,
+                      const float* packed_w_dev, const float* scale_dev, const float* shift_dev, const float* residual_dev,
+                      float* out_dev, long out_batch_stride, long out_pixel_stride, void* out_planes_dev,
+                      long out_plane_stride, int config, int split_k, float* splitk_ws_dev, void* stream) {
+    ConvParams p;
+    int rc = fill_conv_params(d, &p);
+    if (rc) return rc;
+    if (p.M == 0) return SSD_OK;
+    SSD_CHECK_ARG(in_planes_dev && packed_w_dev && out_dev, "conv2d_planes: NULL pointer");
+    SSD_CHECK_ARG(planes == 1 || planes == 3, "conv2d_planes: planes must be 1 (bf16 mode) or 3 (exact split)");
+    SSD_CHECK_ARG(in_plane_stride >= (long)p.B * p.H * p.W * p.Cin, "conv2d_planes: in_plane_stride shorter than the tensor");
+    SSD_CHECK_ARG(!d->has_residual || residual_dev, "conv2d_planes: has_residual set but residual is NULL");
+    SSD_CHECK_ARG(config >= 0 && config < conv_num_configs() && conv_config_is_dma(config), "conv2d_planes: config %d is not an LDS-DMA tile", config);
+    p.xp = static_cast<const short*>(in_planes_dev); p.xp_plane = in_plane_stride; p.xp_np = planes;
+    p.bf16 = planes == 1;
+    p.w = packed_w_dev; p.scale = scale_dev; p.shift = shift_dev;
+    p.w3 = conv_split_planes(packed_w_dev, p.K, p.Cout);
+    p.residual = d->has_residual ? residual_dev : nullptr;
+    p.out = out_dev;
+    p.out_pixel_stride = out_pixel_stride > 0 ? out_pixel_stride : p.Cout;
+    p.out_batch_stride = out_batch_stride > 0 ? out_batch_stride : (long)p.Ho * p.Wo * p.out_pixel_stride;
+    p.vec_store = (((uintptr_t)out_dev & 15) == 0) && (p.out_pixel_stride % 4 == 0) && (p.out_batch_stride % 4 == 0);
+    if (out_planes_dev) {
+        SSD_CHECK_ARG(p.out_pixel_stride == p.Cout && p.out_batch_stride == (long)p.Ho * p.Wo * p.Cout && p.Cout % 4 == 0,
+                      "conv2d_planes: plane output needs a dense [B,Ho,Wo,Cout] destination with Cout %% 4 == 0");
+        SSD_CHECK_ARG(out_plane_stride >= p.M * p.Cout && out_plane_stride % 8 == 0, "conv2d_planes: bad out_plane_stride");
+        p.op = static_cast<short*>(out_planes_dev); p.op_plane = out_plane_stride; p.op_np = planes;
+    }
+    if (split_k > 1) {
+        SSD_CHECK_ARG(splitk_ws_dev != nullptr, "conv2d_planes: split_k > 1 needs a workspace");
+        p.split_k = split_k;
+        p.partial = splitk_ws_dev;
+    }
+    return conv_launch(p, config, (hipStream_t)stream);
 }
 
 size_t ssd_conv_wino_weight_floats(int Cin, int Cout) {

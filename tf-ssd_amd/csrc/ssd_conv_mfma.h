@@ -16,6 +16,126 @@ __device__ __forceinline__ float apply_act(float v, int act) {
     return v;
 }
 
+// The activation as bf16 PLANES for the LDS-DMA tiles of its consumers (ssd_convdma.hip): np = 3 the exact split
+// x = h + m + l (planes h, m, l), np = 1 the bf16 rounding; layout [np][elements] with `plane` elements between planes.
+// Four consecutive channels of one pixel = one 8-byte store per plane.
+__device__ __forceinline__ void store_planes4(short* __restrict__ op, const long plane, const int np, const long e, const f32x4 v) {
+    if (np == 1) {
+        *reinterpret_cast<uint2*>(op + e) = rne4(v);
+    } else {
+        uint2 h, m, l;
+        split4(v, h, m, l);
+        *reinterpret_cast<uint2*>(op + e) = h;
+        *reinterpret_cast<uint2*>(op + plane + e) = m;
+        *reinterpret_cast<uint2*>(op + 2 * plane + e) = l;
+    }
+}
+
+// Epilogue of the implicit-GEMM tiles (shared by conv_mfma_body and the LDS-DMA tiles of ssd_convdma.hip): the lane holds
+// out[m = m0 + (wm * MT + mi) * 16 + (lane & 15)][n = n0 + (wn * NT + ni) * 16 + (lane >> 4) * 4 + 0..3].
+template <int MT, int NT>
+__device__ __forceinline__ void conv_epilogue(const ConvParams& p, f32x4 (&acc)[MT][NT], const long m0, const int n0,
+                                              const int wm, const int wn, const int lane, const int HoWo) {
+    // ---- epilogue: lane holds out[m = .. + (lane & 15)][n = .. + (lane >> 4) * 4 + 0..3]
+    // (M < 2^31 is checked on the host: 32-bit index arithmetic)
+    if (p.split_k > 1) {           // partial sums only; scale/shift/act/residual happen in the reduce
+#pragma unroll
+        for (int mi = 0; mi < MT; ++mi) {
+            const int m = (int)m0 + (wm * MT + mi) * 16 + (lane & 15);
+            if (m >= (int)p.M) continue;
+#pragma unroll
+            for (int ni = 0; ni < NT; ++ni) {
+                const int n = n0 + (wn * NT + ni) * 16 + (lane >> 4) * 4;
+                if (n >= p.Cout) continue;
+                float* prow = p.partial + ((long)blockIdx.y * p.M + m) * p.Cout + n;
+                if (n + 3 < p.Cout && (p.Cout & 3) == 0) {
+                    *reinterpret_cast<f32x4*>(prow) = acc[mi][ni];
+                } else {
+                    for (int j = 0; j < 4; ++j)
+                        if (n + j < p.Cout) prow[j] = acc[mi][ni][j];
+                }
+            }
+        }
+        return;
+    }
+    // All loads of the epilogue are issued first (scale/shift per column group, residual per
+    // tile), the stores follow back to back: a load between two stores costs a full store
+    // round trip on gfx950 (vmcnt counts stores and the waits are not selective).
+    f32x4 sc[NT], sh[NT];
+    bool vecn[NT];
+#pragma unroll
+    for (int ni = 0; ni < NT; ++ni) {
+        const int n = n0 + (wn * NT + ni) * 16 + (lane >> 4) * 4;
+        const bool straddle = p.n_split && n < p.n_split && n + 3 >= p.n_split;
+        vecn[ni] = (n + 3 < p.Cout) && !straddle;
+        sc[ni] = f32x4{1.f, 1.f, 1.f, 1.f};
+        sh[ni] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (vecn[ni]) {
+            if (p.scale) sc[ni] = *reinterpret_cast<const f32x4*>(p.scale + n);
+            if (p.shift) sh[ni] = *reinterpret_cast<const f32x4*>(p.shift + n);
+        }
+    }
+    const bool res_vec = p.residual && (p.Cout & 3) == 0;
+    f32x4 rs[MT][NT];
+    if (res_vec) {
+#pragma unroll
+        for (int mi = 0; mi < MT; ++mi) {
+            const int m = (int)m0 + (wm * MT + mi) * 16 + (lane & 15);
+#pragma unroll
+            for (int ni = 0; ni < NT; ++ni) {
+                const int n = n0 + (wn * NT + ni) * 16 + (lane >> 4) * 4;
+                rs[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (m < (int)p.M && vecn[ni]) rs[mi][ni] = *reinterpret_cast<const f32x4*>(p.residual + (long)m * p.Cout + n);
+            }
+        }
+    }
+#pragma unroll
+    for (int mi = 0; mi < MT; ++mi) {
+        const int m = (int)m0 + (wm * MT + mi) * 16 + (lane & 15);
+        if (m >= (int)p.M) continue;
+        const int b = m / HoWo;
+        const int pix = m - b * HoWo;
+        float* orow = p.out + (long)b * p.out_batch_stride + (long)pix * p.out_pixel_stride;
+        float* orow2 = p.n_split ? p.out2 + (long)b * p.out2_batch_stride + (long)pix * p.out2_pixel_stride - p.n_split : nullptr;
+#pragma unroll
+        for (int ni = 0; ni < NT; ++ni) {
+            const int n = n0 + (wn * NT + ni) * 16 + (lane >> 4) * 4;
+            if (n >= p.Cout) continue;
+            f32x4 v = acc[mi][ni];
+            if (vecn[ni]) {
+                v = v * sc[ni] + sh[ni];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] = apply_act(v[j], p.act);
+                if (res_vec) {
+                    v = v + rs[mi][ni];
+                } else if (p.residual) {
+                    const float* rr = p.residual + (long)m * p.Cout + n;
+                    for (int j = 0; j < 4; ++j) v[j] += rr[j];
+                }
+                const bool side2 = p.n_split && n >= p.n_split;
+                float* dst = (side2 ? orow2 : orow) + n;
+                if ((side2 ? p.vec_store2 : p.vec_store) && ((((uintptr_t)dst) & 15) == 0)) {
+                    *reinterpret_cast<f32x4*>(dst) = v;
+                } else {
+                    dst[0] = v[0]; dst[1] = v[1]; dst[2] = v[2]; dst[3] = v[3];
+                }
+                if (p.op) store_planes4(p.op, p.op_plane, p.op_np, (long)m * p.Cout + n, v);
+            } else {
+                for (int j = 0; j < 4; ++j) {
+                    if (n + j >= p.Cout) break;
+                    float t = v[j];
+                    if (p.scale) t = t * p.scale[n + j];
+                    if (p.shift) t = t + p.shift[n + j];
+                    t = apply_act(t, p.act);
+                    if (p.residual) t += p.residual[(long)m * p.Cout + n + j];
+                    float* drow = (p.n_split && n + j >= p.n_split) ? orow2 : orow;
+                    drow[n + j] = t;
+                }
+            }
+        }
+    }
+}
+
 // Diagnostic builds only (tests/micro/conv_ablate.py): -DSSD_CONV_ABLATE=bits removes one phase
 // of the main loop -- 1 global loads, 2 LDS stores, 4 MFMAs (+ fragment reads), 8 barriers,
 // 16 MFMAs only (fragment reads kept),
@@ -552,103 +672,7 @@ __device__ __forceinline__ void conv_mfma_body(const ConvParams& p, float* __res
     }
     }
 
-    // ---- epilogue: lane holds out[m = .. + (lane & 15)][n = .. + (lane >> 4) * 4 + 0..3]
-    // (M < 2^31 is checked on the host: 32-bit index arithmetic)
-    if (p.split_k > 1) {           // partial sums only; scale/shift/act/residual happen in the reduce
-#pragma unroll
-        for (int mi = 0; mi < MT; ++mi) {
-            const int m = (int)m0 + (wm * MT + mi) * 16 + (lane & 15);
-            if (m >= (int)p.M) continue;
-#pragma unroll
-            for (int ni = 0; ni < NT; ++ni) {
-                const int n = n0 + (wn * NT + ni) * 16 + (lane >> 4) * 4;
-                if (n >= p.Cout) continue;
-                float* prow = p.partial + ((long)blockIdx.y * p.M + m) * p.Cout + n;
-                if (n + 3 < p.Cout && (p.Cout & 3) == 0) {
-                    *reinterpret_cast<f32x4*>(prow) = acc[mi][ni];
-                } else {
-                    for (int j = 0; j < 4; ++j)
-                        if (n + j < p.Cout) prow[j] = acc[mi][ni][j];
-                }
-            }
-        }
-        return;
-    }
-    // All loads of the epilogue are issued first (scale/shift per column group, residual per
-    // tile), the stores follow back to back: a load between two stores costs a full store
-    // round trip on gfx950 (vmcnt counts stores and the waits are not selective).
-    f32x4 sc[NT], sh[NT];
-    bool vecn[NT];
-#pragma unroll
-    for (int ni = 0; ni < NT; ++ni) {
-        const int n = n0 + (wn * NT + ni) * 16 + (lane >> 4) * 4;
-        const bool straddle = p.n_split && n < p.n_split && n + 3 >= p.n_split;
-        vecn[ni] = (n + 3 < p.Cout) && !straddle;
-        sc[ni] = f32x4{1.f, 1.f, 1.f, 1.f};
-        sh[ni] = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (vecn[ni]) {
-            if (p.scale) sc[ni] = *reinterpret_cast<const f32x4*>(p.scale + n);
-            if (p.shift) sh[ni] = *reinterpret_cast<const f32x4*>(p.shift + n);
-        }
-    }
-    const bool res_vec = p.residual && (p.Cout & 3) == 0;
-    f32x4 rs[MT][NT];
-    if (res_vec) {
-#pragma unroll
-        for (int mi = 0; mi < MT; ++mi) {
-            const int m = (int)m0 + (wm * MT + mi) * 16 + (lane & 15);
-#pragma unroll
-            for (int ni = 0; ni < NT; ++ni) {
-                const int n = n0 + (wn * NT + ni) * 16 + (lane >> 4) * 4;
-                rs[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
-                if (m < (int)p.M && vecn[ni]) rs[mi][ni] = *reinterpret_cast<const f32x4*>(p.residual + (long)m * p.Cout + n);
-            }
-        }
-    }
-#pragma unroll
-    for (int mi = 0; mi < MT; ++mi) {
-        const int m = (int)m0 + (wm * MT + mi) * 16 + (lane & 15);
-        if (m >= (int)p.M) continue;
-        const int b = m / HoWo;
-        const int pix = m - b * HoWo;
-        float* orow = p.out + (long)b * p.out_batch_stride + (long)pix * p.out_pixel_stride;
-        float* orow2 = p.n_split ? p.out2 + (long)b * p.out2_batch_stride + (long)pix * p.out2_pixel_stride - p.n_split : nullptr;
-#pragma unroll
-        for (int ni = 0; ni < NT; ++ni) {
-            const int n = n0 + (wn * NT + ni) * 16 + (lane >> 4) * 4;
-            if (n >= p.Cout) continue;
-            f32x4 v = acc[mi][ni];
-            if (vecn[ni]) {
-                v = v * sc[ni] + sh[ni];
-#pragma unroll
-                for (int j = 0; j < 4; ++j) v[j] = apply_act(v[j], p.act);
-                if (res_vec) {
-                    v = v + rs[mi][ni];
-                } else if (p.residual) {
-                    const float* rr = p.residual + (long)m * p.Cout + n;
-                    for (int j = 0; j < 4; ++j) v[j] += rr[j];
-                }
-                const bool side2 = p.n_split && n >= p.n_split;
-                float* dst = (side2 ? orow2 : orow) + n;
-                if ((side2 ? p.vec_store2 : p.vec_store) && ((((uintptr_t)dst) & 15) == 0)) {
-                    *reinterpret_cast<f32x4*>(dst) = v;
-                } else {
-                    dst[0] = v[0]; dst[1] = v[1]; dst[2] = v[2]; dst[3] = v[3];
-                }
-            } else {
-                for (int j = 0; j < 4; ++j) {
-                    if (n + j >= p.Cout) break;
-                    float t = v[j];
-                    if (p.scale) t = t * p.scale[n + j];
-                    if (p.shift) t = t + p.shift[n + j];
-                    t = apply_act(t, p.act);
-                    if (p.residual) t += p.residual[(long)m * p.Cout + n + j];
-                    float* drow = (p.n_split && n + j >= p.n_split) ? orow2 : orow;
-                    drow[n + j] = t;
-                }
-            }
-        }
-    }
+    conv_epilogue<MT, NT>(p, acc, m0, n0, wm, wn, lane, HoWo);
 #ifdef SSD_C3_PROF
     if constexpr (SPLIT3) {
         __syncthreads();

@@ -29,6 +29,14 @@ struct Tensor {
     int H = 0, W = 0, C = 0;
     size_t per_image = 0;     // floats
     float* dev = nullptr;     // arena slot, max_batch images
+    // the same activation as bf16 planes [planes_np][plane_stride] for the LDS-DMA conv tiles of its consumers
+    // (csrc/ssd_convdma.hip): allocated at finalize for every tensor a dense conv with Cin % 32 == 0 reads (option
+    // "conv_dma"), WRITTEN -- by the producer's epilogue or by split_planes_kernel -- only while a running consumer's
+    // chosen configuration is an LDS-DMA tile (planes_live, recomputed per forward)
+    short* planes = nullptr;
+    long plane_stride = 0;    // elements between planes
+    int planes_np = 0;        // 3: exact split h, m, l (fp32 nets); 1: bf16 rounding (the bf16 mode)
+    bool planes_live = false;
 };
 
 struct Layer {
@@ -94,6 +102,7 @@ struct ssd_net {
     int tail_prio = 0;              // 1: extras tail on side[2] (highest priority); 2: its small heads too
     bool tail_on_side = false;      // diagnostics: big heads on the main stream, extras tail + small heads on the side streams
     bool image_split = true;        // fp32 nets: the finalize-time race also times the image kernel's split-bf16 form (img_choice 2; SSD_IMAGE_SPLIT=0 / option "image_split" 0: leave it out)
+    bool conv_dma = true;           // offer the LDS-DMA tiles over pre-split activation planes (ssd_convdma.hip) to the autotune / accept them from tables
     bool image_ticket = false;      // combine the channel-group slabs inside the launch (arrival ticket) instead of by a second launch
     float* img_slabs = nullptr;     // its partial-sum slabs and arrival tickets (sized for max_batch)
     unsigned* img_tickets = nullptr;

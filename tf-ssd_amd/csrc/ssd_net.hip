@@ -307,6 +307,14 @@ static ConvParams layer_conv_params(const ssd_net& net, const Layer& l, int B, c
     p.w = l.packed;
     p.w3 = conv_split_planes(l.packed, l.kh * l.kw * l.Cin, l.Cout);
     p.bf16 = net.precision;
+    if (l.in >= 0 && net.tensors[l.in].planes) {       // the LDS-DMA tiles read the input's bf16 planes
+        const Tensor& ti = net.tensors[l.in];
+        p.xp = ti.planes; p.xp_plane = ti.plane_stride; p.xp_np = ti.planes_np;
+    }
+    if (l.out >= 0 && l.head_kind == 0 && net.tensors[l.out].planes_live && (l.Cout & 3) == 0) {
+        const Tensor& to = net.tensors[l.out];      // ... and a consumer of this layer's output runs on them: the epilogue writes them
+        p.op = to.planes; p.op_plane = to.plane_stride; p.op_np = to.planes_np;
+    }
     p.wino_w = l.wino;
     p.scale = l.scale;
     p.shift = l.shift;
@@ -420,15 +428,37 @@ static int run_layer(ssd_net& net, const Layer& l, int B, float* deltas_out, flo
     return rc;
 }
 
+// fp32 activation -> its bf16 planes (producers without a plane epilogue)
+static int planes_pass(ssd_net& net, int tensor, int B, hipStream_t st) {
+    Tensor& t = net.tensors[tensor];
+    return launch_split_planes(t.dev, (long)B * (long)t.per_image, t.planes_np, t.planes, t.plane_stride, st);
+}
+
+static int run_layer_kernels(ssd_net& net, const Layer& l, int B, float* deltas_out, float* probs_out, hipStream_t st,
+                             int cfg_override);
+
 static int run_layer_impl(ssd_net& net, const Layer& l, int B, float* deltas_out, float* probs_out, hipStream_t st,
                           int cfg_override) {
+    int rc = run_layer_kernels(net, l, B, deltas_out, probs_out, st, cfg_override);
+    if (rc || l.kind == LK_CONV) return rc;       // (convs hand their planes over themselves)
+    if (l.out >= 0 && net.tensors[l.out].planes_live && l.kind != LK_SOFTMAX) rc = planes_pass(net, l.out, B, st);
+    if (!rc && l.kind == LK_FUSED && l.e_out >= 0 && net.tensors[l.e_out].planes_live) rc = planes_pass(net, l.e_out, B, st);
+    return rc;
+}
+
+static int run_layer_kernels(ssd_net& net, const Layer& l, int B, float* deltas_out, float* probs_out, hipStream_t st,
+                             int cfg_override) {
     const float* in = l.in >= 0 ? net.tensors[l.in].dev : nullptr;
     float* out = l.out >= 0 ? net.tensors[l.out].dev : nullptr;
     switch (l.kind) {
         case LK_CONV: {
             const float* res = l.res >= 0 ? net.tensors[l.res].dev : nullptr;
             ConvParams p = layer_conv_params(net, l, B, in, out, res, deltas_out, probs_out);
-            return conv_launch(p, cfg_override >= 0 ? cfg_override : l.cfg, st);
+            const int cfg = cfg_override >= 0 ? cfg_override : l.cfg;
+            const int rc = conv_launch(p, cfg, st);
+            // families without the shared epilogue (Winograd, skinny, VALU direct): the planes come from a pass of their own
+            if (!rc && p.op && !conv_config_writes_planes(cfg)) return planes_pass(net, l.out, B, st);
+            return rc;
         }
         case LK_DW:
             return launch_dwconv3x3(in, B, l.H, l.W, l.Cin, l.stride, l.pt, l.pl, l.Ho, l.Wo,
@@ -609,6 +639,10 @@ static int autotune(ssd_net& net, int B, hipStream_t st) {
                     if (trial == 0 && ms > 1.5f * best) break;      // clearly slower than the incumbent
                 }
                 if (rc) break;
+                // an LDS-DMA tile makes the producer of its input write the bf16 planes as well (6 or 2 bytes per element
+                // at the store rate the epilogues reach): charged to the candidate, the race stays a per-layer one
+                if (conv_config_is_dma(c))
+                    ms += reps * (float)((double)B * net.tensors[l.in].per_image * 2.0 * net.tensors[l.in].planes_np / 3.0e12 * 1e3);
                 if (ms < best) { best = ms; best_cfg = c; best_split = split; }
             }
         }
@@ -967,6 +1001,22 @@ int ssd_net_finalize(ssd_net* net, int max_batch) {
         off += align_up(t.per_image * max_batch, 64) + gap;
     }
     SSD_HIP(hipMemset(net->arena, poison ? 0xFF : 0, total * sizeof(float)));
+    // bf16 planes of every activation a dense conv with Cin % 32 == 0 reads (the LDS-DMA tiles' operand, ssd_convdma.hip);
+    // written only while a consumer's chosen configuration asks for them (planes_live)
+    for (auto& t : net->tensors) { t.planes = nullptr; t.planes_live = false; t.planes_np = 0; t.plane_stride = 0; }
+    if (net->conv_dma)
+        for (const auto& l : net->layers) {
+            if (l.kind != LK_CONV || l.in < 0 || l.Cin % 32 != 0) continue;
+            Tensor& t = net->tensors[l.in];
+            if (t.planes) continue;
+            t.planes_np = net->precision ? 1 : 3;
+            t.plane_stride = (long)align_up(t.per_image * max_batch, 64);
+            float* pl = nullptr;
+            const int rcp = dev_alloc(*net, (size_t)t.planes_np * t.plane_stride / 2 + 64, &pl);
+            if (rcp) return rcp;
+            t.planes = reinterpret_cast<short*>(pl);
+            SSD_HIP(hipMemsetAsync(pl, 0, ((size_t)t.planes_np * t.plane_stride / 2 + 64) * sizeof(float), st));
+        }
     net->max_batch = max_batch;
     // pick tile configurations on the device
     for (auto& l : net->layers) { l.cfg = -1; l.split_k = 1; }
@@ -1125,6 +1175,12 @@ static int forward_impl(ssd_net* net, const float* image_dev, int B, float* delt
     }
     SSD_CHECK_ARG(B >= 0 && B <= net->max_batch, "ssd_net_forward: batch %d exceeds max_batch %d", B, net->max_batch);
     if (B == 0) return SSD_OK;
+    // which activations have to exist as bf16 planes for this forward: the inputs of the running dense convs whose chosen
+    // configuration is an LDS-DMA tile (their producers' epilogues -- or a split pass -- write them)
+    for (auto& t : net->tensors) t.planes_live = false;
+    for (const auto& l : net->layers)
+        if (l.kind == LK_CONV && l.in >= 0 && conv_config_is_dma(l.cfg) && net->tensors[l.in].planes && layer_runs(*net, l))
+            net->tensors[l.in].planes_live = true;
     SSD_CHECK_ARG(image_dev && deltas_out && probs_out, "ssd_net_forward: NULL pointer");
     SSD_CHECK_ARG(((uintptr_t)deltas_out & 15) == 0 && ((uintptr_t)probs_out & 15) == 0,
                   "ssd_net_forward: outputs must be 16-byte aligned");
@@ -1497,6 +1553,12 @@ int ssd_net_set_option(ssd_net* net, const char* name, int value) {
     if (std::string(name) == "use_wino") {       // Winograd F(2x2,3x3) candidates in the autotune (default 1)
         net->use_wino = value != 0;
         net->finalized = false;
+        net->drop_graphs();
+        return SSD_OK;
+    }
+    if (std::string(name) == "conv_dma") {       // LDS-DMA conv tiles over pre-split activation planes (default 1)
+        if (net->conv_dma != (value != 0)) net->finalized = false;
+        net->conv_dma = value != 0;
         net->drop_graphs();
         return SSD_OK;
     }
