@@ -132,33 +132,35 @@ __device__ __forceinline__ void conv_dma_body(const ConvParams& p, char* __restr
     // k-steps of the tile at l_k0 that exist (1x1 path with KS = 2: the last tile may hold one)
     auto steps_here = [&]() -> int { return KS == 1 ? 1 : min(KS, nks - l_k0 / 32); };
 
-    // The DMA of tile kt + 1 is cut into PIECES (one 1 KB wave instruction each: a 16-row block of one plane and k-step)
-    // that are issued BETWEEN the MFMA groups of tile kt: the vector-memory path takes 16 clocks per piece (64 B/clk/CU),
-    // and a burst of all pieces at the top of the iteration blocks every wave at its issue -- matrix pipe idle -- for
-    // ~72 KB / 64 B/clk (measured: the burst form ran at the speed of the register-staged tiles); spread out, a piece
-    // costs its issue slot.  The two stages alternate; a stage is refilled after the barrier that follows its last read.
-    constexpr int PX = RPX * KS * NP, NPIECES = (RPX + RPW) * KS * NP;
-    int xvo[RPX];                               // this tile's buffer offset per X row block (2^31: zero-fill)
-    auto prepare = [&]() {                      // after tile_setup / tile_advance: the l_* state describes the tile to fetch
+    auto issue = [&](int stage) {              // DMA of the tile described by the l_* state into `stage`
+        char* sb = dsm + stage * STAGE;
+        const int ns = steps_here();
 #pragma unroll
         for (int j = 0; j < RPX; ++j) {
+            const int rb = wave + j * NW;
+            if (RBX % NW != 0 && rb >= RBX) continue;
             const bool ok = GEMM1X1 ? (xvalid[j] != 0) : (((xvalid[j] >> l_tap) & 1u) != 0);
-            xvo[j] = ok ? xoff[j] + l_xtile : (int)0x80000000;
+            const int vo = ok ? xoff[j] + l_xtile : (int)0x80000000;
+#pragma unroll
+            for (int s = 0; s < KS; ++s) {
+                if (KS > 1 && s >= ns) break;
+#pragma unroll
+                for (int pl = 0; pl < NP; ++pl)
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(xrs[pl], (lds_dst_t)(sb + ((s * NP + pl) * BM + rb * 16) * 64), 16, vo, s * 64, 0, 0);
+            }
         }
-    };
-    auto issue_piece = [&](const int pc, char* sb, const int ns, const int k0) {      // pc: compile-time after unrolling
-        if (pc < PX) {
-            const int j = pc / (KS * NP), s = (pc / NP) % KS, pl = pc % NP;
+#pragma unroll
+        for (int j = 0; j < RPW; ++j) {
             const int rb = wave + j * NW;
-            if ((RBX % NW != 0 && rb >= RBX) || (KS > 1 && s >= ns)) return;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(xrs[pl], (lds_dst_t)(sb + ((s * NP + pl) * BM + rb * 16) * 64), 16, xvo[j], s * 64, 0, 0);
-        } else {
-            const int q = pc - PX;
-            const int j = q / (KS * NP), s = (q / NP) % KS, pl = q % NP;
-            const int rb = wave + j * NW;
-            if ((RBW % NW != 0 && rb >= RBW) || (KS > 1 && s >= ns)) return;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(wrs, (lds_dst_t)(sb + XBYTES + ((s * NP + pl) * BN + rb * 16) * 64), 16, woff[j],
-                                                     (int)((pl + WPL) * wplane_b) + (k0 + s * 32) * 2, 0, 0);
+            if (RBW % NW != 0 && rb >= RBW) continue;
+#pragma unroll
+            for (int s = 0; s < KS; ++s) {
+                if (KS > 1 && s >= ns) break;
+#pragma unroll
+                for (int pl = 0; pl < NP; ++pl)
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(wrs, (lds_dst_t)(sb + XBYTES + ((s * NP + pl) * BN + rb * 16) * 64), 16, woff[j],
+                                                             (int)((pl + WPL) * wplane_b) + (l_k0 + s * 32) * 2, 0, 0);
+            }
         }
     };
 
@@ -170,45 +172,28 @@ __device__ __forceinline__ void conv_dma_body(const ConvParams& p, char* __restr
 
     const int frow = lane & 15;
     const int fq = ((lane >> 4) ^ ((frow >> 1) & 3)) << 4;
-    constexpr int NGROUPS = KS * NT;            // MFMA groups (one weight fragment x MT pixel fragments) per tile
-    // multiply the tile in `stage` (ns k-steps); between its MFMA groups issue the pieces of the NEXT tile (if any) into `nb`
-    auto mma_tile = [&](const int stage, const int ns, const bool fetch, char* nb, const int ns_next, const int k0_next) {
+    auto mma_tile = [&](int stage, int ns) {
         const char* sb = dsm + stage * STAGE;
 #pragma unroll
         for (int s = 0; s < KS; ++s) {
-            const bool live = !(KS > 1 && s >= ns);
+            if (KS > 1 && s >= ns) break;
             const char* Xb = sb + s * NP * BM * 64;
             const char* Wb = sb + XBYTES + s * NP * BN * 64;
             BP<NP> b[MT];
-            if (live) {
 #pragma unroll
-                for (int mi = 0; mi < MT; ++mi) {
-                    const char* r = Xb + ((wm * MT + mi) * 16 + frow) * 64 + fq;
+            for (int mi = 0; mi < MT; ++mi) {
+                const char* r = Xb + ((wm * MT + mi) * 16 + frow) * 64 + fq;
 #pragma unroll
-                    for (int pl = 0; pl < NP; ++pl) b[mi].p[pl] = *reinterpret_cast<const bf16x8*>(r + pl * BM * 64);
-                }
+                for (int pl = 0; pl < NP; ++pl) b[mi].p[pl] = *reinterpret_cast<const bf16x8*>(r + pl * BM * 64);
             }
 #pragma unroll
             for (int ni = 0; ni < NT; ++ni) {
-                if (live) {
-                    const char* r = Wb + ((wn * NT + ni) * 16 + frow) * 64 + fq;
-                    BP<NP> a;
+                const char* r = Wb + ((wn * NT + ni) * 16 + frow) * 64 + fq;
+                BP<NP> a;
 #pragma unroll
-                    for (int pl = 0; pl < NP; ++pl) a.p[pl] = *reinterpret_cast<const bf16x8*>(r + pl * BN * 64);
+                for (int pl = 0; pl < NP; ++pl) a.p[pl] = *reinterpret_cast<const bf16x8*>(r + pl * BN * 64);
 #pragma unroll
-                    for (int mi = 0; mi < MT; ++mi) acc[mi][ni] = mmaN<NP>(a, b[mi], acc[mi][ni]);
-                }
-                // the pieces follow the first NGROUPS - 1 groups, evenly: none behind the last one (its pieces would meet the
-                // barrier's vmcnt(0) with their whole latency exposed)
-                const int g = s * NT + ni;
-                constexpr int SLOTS = NGROUPS > 1 ? NGROUPS - 1 : 1;
-                if (fetch && g < SLOTS) {
-                    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                    for (int pc = 0; pc < NPIECES; ++pc)
-                        if (pc * SLOTS / NPIECES == g) issue_piece(pc, nb, ns_next, k0_next);
-                    __builtin_amdgcn_sched_barrier(0);
-                }
+                for (int mi = 0; mi < MT; ++mi) acc[mi][ni] = mmaN<NP>(a, b[mi], acc[mi][ni]);
             }
         }
     };
@@ -217,21 +202,18 @@ __device__ __forceinline__ void conv_dma_body(const ConvParams& p, char* __restr
     if (kt_begin < kt_end) {
         tile_setup(kt_begin);
         ns_cur = steps_here();
-        prepare();
-#pragma unroll
-        for (int pc = 0; pc < NPIECES; ++pc) issue_piece(pc, dsm, ns_cur, l_k0);
+        issue(0);
     }
     __syncthreads();                 // (s_waitcnt vmcnt(0) + s_barrier: the DMA counts on vmcnt)
     for (int kt = kt_begin; kt < kt_end; ++kt) {
         const int stage = (kt - kt_begin) & 1;
-        const bool more = kt + 1 < kt_end;
         int ns_next = 1;
-        if (more) {
+        if (kt + 1 < kt_end) {
             tile_advance();
             ns_next = steps_here();
-            prepare();
+            issue(stage ^ 1);        // lands while this tile is multiplied; the stage was last read before the previous barrier
         }
-        mma_tile(stage, ns_cur, more, dsm + (stage ^ 1) * STAGE, ns_next, l_k0);
+        mma_tile(stage, ns_cur);
         ns_cur = ns_next;
         __syncthreads();
     }
