@@ -749,6 +749,7 @@ ssd_net* ssd_net_create(int backbone, int img_size, int levels, const int* n_ars
     if (const char* g = getenv("SSD_TAIL_PRIO")) net->tail_prio = atoi(g) < 0 ? 0 : (atoi(g) > 2 ? 2 : atoi(g));    // diagnostics
     if (const char* g = getenv("SSD_FUSE_SOFTMAX")) net->fuse_softmax = atoi(g) != 0;    // diagnostics (A/B of the decoder tail)
     if (const char* g = getenv("SSD_IMAGE_SPLIT")) net->image_split = atoi(g) != 0;      // diagnostics (A/B of the image kernel's forms)
+    if (const char* g = getenv("SSD_HIP_CONV_DMA")) net->conv_dma = atoi(g) != 0;         // diagnostics (A/B of the LDS-DMA conv tiles)
     if (const char* g = getenv("SSD_HIP_USE_GRAPH")) {      // diagnostics: pin the launch mode (0 direct, 1 graph replay)
         net->use_graph = atoi(g) != 0 && !net->graphs_unsafe;
         net->use_graph_auto = false;
