@@ -292,6 +292,10 @@ int ssd_net_predict(ssd_net* net, const float* image_dev, int B, const float* pr
 /* Debug/test hook: copy the activation of a named layer of the LAST forward to the host.
  * Returns the element count (or negative error); host_out may be NULL to query size. */
 long ssd_net_fetch_activation(ssd_net* net, const char* layer, float* host_out, size_t cap);
+/* ... and the same activation as the bf16 planes the LDS-DMA conv tiles read (csrc/ssd_convdma.hip), joined back to
+ * fp32: *planes_out = 3 (exact split: equals the fp32 activation bit for bit) or 1 (its bf16 rounding); returns 0 when
+ * no running layer asked for this tensor's planes in the last forward. */
+long ssd_net_fetch_planes(ssd_net* net, const char* layer, float* host_out, size_t cap, int* planes_out);
 
 /* Per-layer algorithmic work of one forward at batch B (for roofline accounting). */
 int ssd_net_num_layers(const ssd_net* net);

@@ -202,3 +202,67 @@ def test_dma_tiles_refuse_what_they_cannot_run():
     assert rc == -3
     rc, _ = run_conv(x, w, pads=(1, 1, 1, 1), cfg=cfg)                   # fp32 entry point: no planes
     assert rc == -3
+
+
+@pytest.mark.parametrize("backbone,prec,B", [("mobilenet_v2", "fp32", 4), ("vgg16", "fp32", 2), ("mobilenet_v2", "bf16", 4), ("vgg16", "bf16", 2)])
+def test_nets_on_lds_dma_tiles(backbone, prec, B):
+    """Whole nets with the register-staged tiles of a kernel table replaced by their LDS-DMA twins (same tile shape,
+    same split-K; ``set_tuning``): the producers' epilogues (conv / split-K reduce / max-pool / L2 normalisation / VGG stem /
+    whole-image block kernel incl. block 13's expanded map and the combine launch) or a split pass write the bf16 planes.
+    fp32 nets: network outputs BITWISE those of the ``mfma3_*`` table (exact planes, same K walk, same product order);
+    bf16 nets: the planes ARE the mode's rounding of the activation, only the K-slice grouping differs (64 instead of 32
+    channels per tap visit): outputs within accumulation-order noise.  Every live plane tensor is checked against the fp32
+    activation it mirrors."""
+    import ssd_hip as h
+    import helpers
+    lib = h.lib()
+    get_model = __import__("models.ssd_%s" % backbone, fromlist=["get_model"]).get_model
+    hp = helpers.hyper_params(backbone)
+    w = helpers.synthetic_weights(backbone, hp)
+    x = helpers.images(B, 300, seed=9)
+    ref = get_model(hp, max_batch=B, precision=prec)
+    ref.set_option("conv_dma", 0)
+    ref.set_weights(w)
+    d0, p0 = [_np(t) for t in ref(x)]
+    names = {lib.ssd_conv_config_name(c).decode() for c in range(lib.ssd_conv_num_configs())}
+    src, dst = ("mfma3_", "dma3_") if prec == "fp32" else ("bf16_", "dmab_")
+    lines, swapped = [], 0
+    for l in ref.get_tuning().splitlines():
+        parts = l.split(" ")
+        if len(parts) == 3 and parts[1].startswith(src) and dst + parts[1][len(src):] in names:
+            parts[1] = dst + parts[1][len(src):]
+            swapped += 1
+        lines.append(" ".join(parts))
+    assert swapped >= 3, "the reference table holds too few %s* lines to swap" % src
+    m = get_model(hp, max_batch=B, precision=prec)
+    m.set_weights(w)
+    m.set_tuning("\n".join(lines) + "\n")
+    d1, p1 = [_np(t) for t in m(x)]
+    ran = [r for r in m.layers(B) if r["config"].startswith(dst) and r["flops"] > 0]
+    # (a swapped line whose layer has Cin % 32 != 0 -- or % 64 in the bf16 form -- falls back to the autotune: fine)
+    assert len(ran) >= 3, "too few layers ran on %s* tiles: %s" % (dst, [r["config"] for r in m.layers(B)])
+    if prec == "fp32":
+        np.testing.assert_array_equal(d1.view(np.uint32), d0.view(np.uint32))
+        np.testing.assert_array_equal(p1.view(np.uint32), p0.view(np.uint32))
+    else:
+        print("%s bf16, %d layers on dmab tiles: probs max |d| %.2e, deltas %.2e" % (backbone, len(ran), np.abs(p1 - p0).max(), np.abs(d1 - d0).max()))
+        assert np.abs(p1 - p0).max() <= 2e-3 and np.abs(d1 - d0).max() <= 2e-2 * max(1.0, np.abs(d0).max())
+    checked = 0
+    for r in m.layers(B):
+        try:
+            pl, npl = m.fetch_planes(r["name"])
+        except ValueError:
+            continue
+        if pl is None:
+            continue
+        act = m.fetch_activation(r["name"])
+        assert npl == (3 if prec == "fp32" else 1)
+        want = act if npl == 3 else bf16_round(act)
+        np.testing.assert_array_equal(pl.view(np.uint32), want.view(np.uint32), err_msg="planes of %s" % r["name"])
+        checked += 1
+    assert checked >= 2, checked
+    # the LDS-DMA option off: no planes, same results as the reference
+    m.set_option("conv_dma", 0)
+    m.set_tuning(None)
+    d2, p2 = [_np(t) for t in m(x)]
+    np.testing.assert_array_equal(p2, p0)

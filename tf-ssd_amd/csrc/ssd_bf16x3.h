@@ -117,4 +117,19 @@ __device__ __forceinline__ void pack_planes(float x, int bf16_mode, short& h, sh
     else split1(x, h, m, l);
 }
 
+// The activation as bf16 PLANES for the LDS-DMA tiles of its consumers (ssd_convdma.hip): np = 3 the exact split
+// x = h + m + l (planes h, m, l), np = 1 the bf16 rounding; layout [np][elements] with `plane` elements between planes.
+// Four consecutive channels of one pixel = one 8-byte store per plane.
+__device__ __forceinline__ void store_planes4(short* __restrict__ op, const long plane, const int np, const long e, const b3_f32x4 v) {
+    if (np == 1) {
+        *reinterpret_cast<uint2*>(op + e) = rne4(v);
+    } else {
+        uint2 h, m, l;
+        split4(v, h, m, l);
+        *reinterpret_cast<uint2*>(op + e) = h;
+        *reinterpret_cast<uint2*>(op + plane + e) = m;
+        *reinterpret_cast<uint2*>(op + 2 * plane + e) = l;
+    }
+}
+
 }  // namespace ssd

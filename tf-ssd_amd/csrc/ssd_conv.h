@@ -71,6 +71,13 @@ struct FusedBlockParams {
     float* slabs;               // [G][B][Ho*Wo][Cout] partial sums (G > 1)
     unsigned* tickets;          // [B] arrival counters, zero between launches
     float* e_out;               // optional: the expanded map [B,H,W,Ce] is ALSO written to HBM (block 13: SSD feature map 1)
+    // optional bf16 planes of the outputs for the LDS-DMA conv tiles that read them (csrc/ssd_convdma.hip): y (written by
+    // the direct epilogue / the combine launch) and the expanded map e_out; planes_np = 3 exact split, 1 bf16 rounding
+    short* y_planes;
+    long y_plane;
+    short* e_planes;
+    long e_plane;
+    int planes_np;
     long long* dbg;             // optional per-phase cycle counters [blocks][8] (profiling builds)
     int ablate;                 // diagnostics: 1 skip expand MFMAs, 2 skip depthwise math, 4 skip project MFMAs, 8 skip expand epilogue math
 };
@@ -185,14 +192,15 @@ int dma_launch(const ConvParams& p, int i, int np, hipStream_t st);
 int launch_split_planes(const float* x, long n, int np, short* planes, long plane, hipStream_t st);
 int launch_join_planes(const short* planes, long n, int np, long plane, float* x, hipStream_t st);
 bool conv_config_is_dma(int cfg);          // either family
-bool conv_config_writes_planes(int cfg);   // the family's epilogue (conv_epilogue / splitk_reduce_kernel) honours ConvParams::op
+bool conv_config_writes_planes(int cfg, const ConvParams& p);   // the family's epilogue (conv_epilogue / splitk_reduce_kernel) honours ConvParams::op
 
 int launch_dwconv3x3(const float* in, int B, int H, int W, int C, int stride, int pad_t, int pad_l,
                      int Ho, int Wo, const float* w, const float* scale, const float* shift, int act,
                      float* out, hipStream_t st);
 int launch_maxpool(const float* in, int B, int H, int W, int C, int k, int stride, int pad_t, int pad_l,
-                   int Ho, int Wo, float* out, hipStream_t st);
-int launch_l2norm(const float* in, long pixels, int C, const float* gamma, float* out, hipStream_t st);
+                   int Ho, int Wo, float* out, hipStream_t st, short* planes = nullptr, long plane = 0, int np = 0);
+int launch_l2norm(const float* in, long pixels, int C, const float* gamma, float* out, hipStream_t st,
+                  short* planes = nullptr, long plane = 0, int np = 0);
 int launch_softmax(const float* in, long rows, int L, float* out, hipStream_t st);
 // (csrc/ssd_bbox.hip) the SSDDecoder with the softmax fused into its compaction kernel: head LOGITS in; `ws` is a
 // workspace of ssd_decode_nms_workspace_bytes(ws_batch, ...) -- carved for ws_batch >= B images whatever B a call runs --

@@ -207,8 +207,9 @@ __global__ __launch_bounds__(256) void conv_stem_kernel(const ConvParams p) {
                 if (m >= p.M) continue;
                 const int b = (int)(m / HoWo);
                 const long pix = m - (long)b * HoWo;
-                *reinterpret_cast<f32x4*>(p.out + (long)b * p.out_batch_stride + pix * p.out_pixel_stride + cg + c4 * 4) =
-                    *reinterpret_cast<const f32x4*>(so + pl * 36 + c4 * 4);
+                const f32x4 v = *reinterpret_cast<const f32x4*>(so + pl * 36 + c4 * 4);
+                *reinterpret_cast<f32x4*>(p.out + (long)b * p.out_batch_stride + pix * p.out_pixel_stride + cg + c4 * 4) = v;
+                if (p.op) store_planes4(p.op, p.op_plane, p.op_np, m * p.Cout + cg + c4 * 4, v);      // (dense outputs only)
             }
         }
     }
@@ -299,7 +300,8 @@ static int direct_cfg() { return dma3_cfg0() + 2 * dma_num_configs(); }
 #define kDmabCfg0 dmab_cfg0()
 #define kDirectCfg direct_cfg()
 bool conv_config_is_dma(int cfg) { return cfg >= kDma3Cfg0 && cfg < kDirectCfg; }
-bool conv_config_writes_planes(int cfg) {
+bool conv_config_writes_planes(int cfg, const ConvParams& p) {
+    if (cfg == kDirectCfg) return stem_ok(p);              // the RGB stem kernel does, the generic VALU kernel does not
     return (cfg >= 0 && cfg < kNumMfmaCfgs) || (cfg >= kMfma3Cfg0 && cfg < kDirectCfg);      // fp32-MFMA, split-bf16, bf16 and LDS-DMA tiles
 }
 

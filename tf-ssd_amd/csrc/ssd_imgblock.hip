@@ -228,8 +228,11 @@ __global__ __launch_bounds__(kIThreads) void mbv2_image_block_kernel(const Fused
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] = __builtin_amdgcn_fmed3f(v[e], 0.0f, hi);
             if (tvalid[t]) *reinterpret_cast<f32x4*>(es + qs[t] * kILD) = v;
-            if (p.e_out && real[t])
-                *reinterpret_cast<f32x4*>(p.e_out + ((long)img * H * W + opix[t]) * p.Ce + cbeg + j * kIC + g4 * 4) = v;
+            if (p.e_out && real[t]) {
+                const long eo = ((long)img * H * W + opix[t]) * p.Ce + cbeg + j * kIC + g4 * 4;
+                *reinterpret_cast<f32x4*>(p.e_out + eo) = v;
+                if (p.e_planes) store_planes4(p.e_planes, p.e_plane, p.planes_np, eo, v);
+            }
         }
     };
 
@@ -320,6 +323,7 @@ __global__ __launch_bounds__(kIThreads) void mbv2_image_block_kernel(const Fused
                 if (p.residual)                                     // Cin == Cout: same layout as y
                     v = v + *reinterpret_cast<const f32x4*>(p.x + img_off + (long)opo[t] * p.Cout + ni * 16 + g4 * 4);
                 *reinterpret_cast<f32x4*>(yp + ni * 16) = v;
+                if (p.y_planes) store_planes4(p.y_planes, p.y_plane, p.planes_np, img_off + (long)opo[t] * p.Cout + g4 * 4 + ni * 16, v);
             }
         }
         ITICK(5);
@@ -585,8 +589,11 @@ __global__ __launch_bounds__(kIThreads) void mbv2_image16_block_kernel(const Fus
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] = __builtin_amdgcn_fmed3f(v[e], 0.0f, hi);
             if (tvalid[t]) *reinterpret_cast<f32x4*>(es + qs[t] * kILD) = v;
-            if (p.e_out && real[t])
-                *reinterpret_cast<f32x4*>(p.e_out + ((long)img * H * W + opix[t]) * p.Ce + cbeg + j * kIC + g4 * 4) = v;
+            if (p.e_out && real[t]) {
+                const long eo = ((long)img * H * W + opix[t]) * p.Ce + cbeg + j * kIC + g4 * 4;
+                *reinterpret_cast<f32x4*>(p.e_out + eo) = v;
+                if (p.e_planes) store_planes4(p.e_planes, p.e_plane, p.planes_np, eo, v);
+            }
         }
     };
 
@@ -686,6 +693,7 @@ __global__ __launch_bounds__(kIThreads) void mbv2_image16_block_kernel(const Fus
                 if (p.residual)
                     v = v + *reinterpret_cast<const f32x4*>(p.x + img_off + (long)opo[t] * p.Cout + ni * 16 + g4 * 4);
                 *reinterpret_cast<f32x4*>(yp + ni * 16) = v;
+                if (p.y_planes) store_planes4(p.y_planes, p.y_plane, p.planes_np, img_off + (long)opo[t] * p.Cout + g4 * 4 + ni * 16, v);
             }
         }
         I16TICK(5);
@@ -711,7 +719,8 @@ __global__ __launch_bounds__(kIThreads) void mbv2_image16_block_kernel(const Fus
 // y = shift + sum of the G slabs in group order (+ residual): the combine as its own launch
 __global__ __launch_bounds__(256) void image_combine_kernel(const float* __restrict__ slabs, const float* __restrict__ ph,
                                                             const float* __restrict__ xres, float* __restrict__ y,
-                                                            long nvec, long slab_vec, int G, int c4n) {
+                                                            long nvec, long slab_vec, int G, int c4n, short* __restrict__ yp,
+                                                            long y_plane, int np) {
     for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < nvec; e += (long)gridDim.x * 256) {
         f32x4 v = *reinterpret_cast<const f32x4*>(ph + (e % c4n) * 4);
         f32x4 s[4];
@@ -725,6 +734,7 @@ __global__ __launch_bounds__(256) void image_combine_kernel(const float* __restr
         }
         if (xres) v = v + *reinterpret_cast<const f32x4*>(xres + e * 4);
         *reinterpret_cast<f32x4*>(y + e * 4) = v;
+        if (yp) store_planes4(yp, y_plane, np, e * 4, v);
     }
 }
 
@@ -842,7 +852,7 @@ int launch_image_block(FusedBlockParams p, hipStream_t st) {
         const long nvec = (long)p.B * p.Ho * p.Wo * p.Cout / 4;
         const int blocks = (int)((nvec + 255) / 256 < 4096 ? (nvec + 255) / 256 : 4096);
         hipLaunchKernelGGL(image_combine_kernel, dim3(blocks), dim3(256), 0, st, p.slabs, p.ph, p.residual ? p.x : nullptr, p.y,
-                           nvec, nvec, p.groups, p.Cout / 4);
+                           nvec, nvec, p.groups, p.Cout / 4, p.y_planes, p.y_plane, p.planes_np);
         SSD_LAUNCH_CHECK();
     }
     return SSD_OK;

@@ -364,6 +364,14 @@ static FusedBlockParams fused_params(const ssd_net& net, const Layer& f, int B) 
     p.kpad_p = conv_kpad(lp.Cin);
     p.npad_p = conv_npad(lp.Cout);
     p.e_out = f.e_out >= 0 ? net.tensors[f.e_out].dev : nullptr;
+    if (f.out >= 0 && net.tensors[f.out].planes_live) {           // (honoured by the whole-image kernel; the band kernels take a split pass)
+        const Tensor& to = net.tensors[f.out];
+        p.y_planes = to.planes; p.y_plane = to.plane_stride; p.planes_np = to.planes_np;
+    }
+    if (f.e_out >= 0 && net.tensors[f.e_out].planes_live) {
+        const Tensor& te = net.tensors[f.e_out];
+        p.e_planes = te.planes; p.e_plane = te.plane_stride; p.planes_np = te.planes_np;
+    }
     p.we3 = reinterpret_cast<const short*>(f.fz_we3);        // band kernel's plane layout (blocks 1-6) ...
     p.wp3 = reinterpret_cast<const short*>(f.fz_wp3);
     p.bf16 = net.precision;
@@ -440,8 +448,11 @@ static int run_layer_kernels(ssd_net& net, const Layer& l, int B, float* deltas_
 static int run_layer_impl(ssd_net& net, const Layer& l, int B, float* deltas_out, float* probs_out, hipStream_t st,
                           int cfg_override) {
     int rc = run_layer_kernels(net, l, B, deltas_out, probs_out, st, cfg_override);
-    if (rc || l.kind == LK_CONV) return rc;       // (convs hand their planes over themselves)
-    if (l.out >= 0 && net.tensors[l.out].planes_live && l.kind != LK_SOFTMAX) rc = planes_pass(net, l.out, B, st);
+    // convs, pools, the L2 normalisation and the whole-image block kernel write their planes themselves
+    if (rc || l.kind == LK_CONV || l.kind == LK_POOL || l.kind == LK_L2NORM || l.kind == LK_SOFTMAX) return rc;
+    const bool image_form = l.kind == LK_FUSED && l.f_type == 0 && !net.image_ticket && !fused_block_supported(fused_params(net, l, B));
+    if (image_form) return rc;
+    if (l.out >= 0 && net.tensors[l.out].planes_live) rc = planes_pass(net, l.out, B, st);
     if (!rc && l.kind == LK_FUSED && l.e_out >= 0 && net.tensors[l.e_out].planes_live) rc = planes_pass(net, l.e_out, B, st);
     return rc;
 }
@@ -457,16 +468,22 @@ static int run_layer_kernels(ssd_net& net, const Layer& l, int B, float* deltas_
             const int cfg = cfg_override >= 0 ? cfg_override : l.cfg;
             const int rc = conv_launch(p, cfg, st);
             // families without the shared epilogue (Winograd, skinny, VALU direct): the planes come from a pass of their own
-            if (!rc && p.op && !conv_config_writes_planes(cfg)) return planes_pass(net, l.out, B, st);
+            if (!rc && p.op && !conv_config_writes_planes(cfg, p)) return planes_pass(net, l.out, B, st);
             return rc;
         }
         case LK_DW:
             return launch_dwconv3x3(in, B, l.H, l.W, l.Cin, l.stride, l.pt, l.pl, l.Ho, l.Wo,
                                     net.params[l.p_kernel].dev, l.scale, l.shift, l.act, out, st);
-        case LK_POOL:
-            return launch_maxpool(in, B, l.H, l.W, l.Cin, l.kh, l.stride, l.pt, l.pl, l.Ho, l.Wo, out, st);
-        case LK_L2NORM:
-            return launch_l2norm(in, (long)B * l.H * l.W, l.Cin, net.params[l.p_gamma].dev, out, st);
+        case LK_POOL: {
+            const Tensor& to = net.tensors[l.out];
+            return launch_maxpool(in, B, l.H, l.W, l.Cin, l.kh, l.stride, l.pt, l.pl, l.Ho, l.Wo, out, st,
+                                  to.planes_live ? to.planes : nullptr, to.plane_stride, to.planes_np);
+        }
+        case LK_L2NORM: {
+            const Tensor& to = net.tensors[l.out];
+            return launch_l2norm(in, (long)B * l.H * l.W, l.Cin, net.params[l.p_gamma].dev, out, st,
+                                 to.planes_live ? to.planes : nullptr, to.plane_stride, to.planes_np);
+        }
         case LK_SOFTMAX:
             return launch_softmax(probs_out, (long)B * net.num_priors, net.L, probs_out, st);
         case LK_FUSED:
@@ -1621,6 +1638,36 @@ long ssd_net_fetch_activation(ssd_net* net, const char* layer, float* host_out, 
     }
     if (hipDeviceSynchronize() != hipSuccess || hipMemcpy(host_out, t.dev, n * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess) {
         set_error("ssd_net_fetch_activation: copy failed");
+        return SSD_E_HIP;
+    }
+    return (long)n;
+}
+
+// ... and its bf16 planes (the LDS-DMA conv tiles' operand) joined back to fp32: 0 when no running consumer asked for
+// them in the last forward; *planes_out = 3 (exact split) or 1 (bf16 rounding)
+long ssd_net_fetch_planes(ssd_net* net, const char* layer, float* host_out, size_t cap, int* planes_out) {
+    if (!net || !layer) return SSD_E_INVALID;
+    auto it = net->tensor_index.find(layer);
+    if (it == net->tensor_index.end()) {
+        set_error("ssd_net_fetch_planes: unknown tensor '%s'", layer);
+        return SSD_E_INVALID;
+    }
+    const Tensor& t = net->tensors[it->second];
+    if (planes_out) *planes_out = t.planes_np;
+    if (!t.planes || !t.planes_live) return 0;
+    const size_t n = t.per_image * (size_t)net->last_batch;
+    if (!host_out) return (long)n;
+    if (cap < n) {
+        set_error("ssd_net_fetch_planes: buffer holds %zu floats, need %zu", cap, n);
+        return SSD_E_INVALID;
+    }
+    ScopedDev tmp;
+    SSD_HIP(hipMalloc((void**)&tmp.p, n * sizeof(float)));
+    SSD_HIP(hipDeviceSynchronize());
+    const int rc = launch_join_planes(t.planes, (long)n, t.planes_np, t.plane_stride, tmp.p, nullptr);
+    if (rc) return rc;
+    if (hipDeviceSynchronize() != hipSuccess || hipMemcpy(host_out, tmp.p, n * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess) {
+        set_error("ssd_net_fetch_planes: copy failed");
         return SSD_E_HIP;
     }
     return (long)n;

@@ -1,6 +1,7 @@
 // HBM-bound NHWC ops for gfx950: depthwise 3x3 (+BN +ReLU6), MaxPool (TF SAME), channel
 // L2 normalisation, row softmax, BatchNorm folding.  All use 16-byte channel-vector
 // accesses (4 fp32 channels per lane, lanes consecutive along C => coalesced).
+#include "ssd_bf16x3.h"
 #include "ssd_conv.h"
 
 namespace ssd {
@@ -101,7 +102,8 @@ int launch_dwconv3x3(const float* in, int B, int H, int W, int C, int stride, in
 __global__ __launch_bounds__(256) void maxpool_kernel(const float* __restrict__ in, const int B, const int H,
                                                       const int W, const int C, const int k, const int stride,
                                                       const int pad_t, const int pad_l, const int Ho,
-                                                      const int Wo, float* __restrict__ out) {
+                                                      const int Wo, float* __restrict__ out, short* __restrict__ planes,
+                                                      const long plane, const int np) {
     const int C4 = C >> 2;
     const long total = (long)B * Ho * Wo * C4;
     for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
@@ -124,16 +126,17 @@ __global__ __launch_bounds__(256) void maxpool_kernel(const float* __restrict__ 
             }
         }
         *reinterpret_cast<f32x4*>(out + e * 4) = m;
+        if (planes) store_planes4(planes, plane, np, e * 4, m);      // the bf16 planes the LDS-DMA conv tiles read (ssd_convdma.hip)
     }
 }
 
 int launch_maxpool(const float* in, int B, int H, int W, int C, int k, int stride, int pad_t, int pad_l,
-                   int Ho, int Wo, float* out, hipStream_t st) {
+                   int Ho, int Wo, float* out, hipStream_t st, short* planes, long plane, int np) {
     const long total = (long)B * Ho * Wo * (C / 4);
     if (total == 0) return SSD_OK;
     const int blocks = (int)(cdiv(total, 256) < 16384 ? cdiv(total, 256) : 16384);
     hipLaunchKernelGGL(maxpool_kernel, dim3(blocks), dim3(256), 0, st, in, B, H, W, C, k, stride, pad_t, pad_l,
-                       Ho, Wo, out);
+                       Ho, Wo, out, planes, plane, np);
     SSD_LAUNCH_CHECK();
     return SSD_OK;
 }
@@ -142,7 +145,8 @@ int launch_maxpool(const float* in, int B, int H, int W, int C, int k, int strid
 // One wave per pixel: lanes stride over C in float4, 64-wide butterfly reduction.
 __global__ __launch_bounds__(256) void l2norm_kernel(const float* __restrict__ in, const long pixels,
                                                      const int C, const float* __restrict__ gamma,
-                                                     float* __restrict__ out) {
+                                                     float* __restrict__ out, short* __restrict__ planes, const long plane,
+                                                     const int np) {
     const int lane = threadIdx.x & 63;
     const long wave0 = ((long)blockIdx.x * 256 + threadIdx.x) >> 6;
     const long nwaves = ((long)gridDim.x * 256) >> 6;
@@ -159,15 +163,18 @@ __global__ __launch_bounds__(256) void l2norm_kernel(const float* __restrict__ i
         for (int c = lane * 4; c < C; c += 256) {
             const f32x4 v = *reinterpret_cast<const f32x4*>(x + c);
             const f32x4 g = *reinterpret_cast<const f32x4*>(gamma + c);
-            *reinterpret_cast<f32x4*>(out + px * C + c) = v * inv * g;
+            const f32x4 y = v * inv * g;
+            *reinterpret_cast<f32x4*>(out + px * C + c) = y;
+            if (planes) store_planes4(planes, plane, np, px * C + c, y);
         }
     }
 }
 
-int launch_l2norm(const float* in, long pixels, int C, const float* gamma, float* out, hipStream_t st) {
+int launch_l2norm(const float* in, long pixels, int C, const float* gamma, float* out, hipStream_t st, short* planes,
+                  long plane, int np) {
     if (pixels == 0) return SSD_OK;
     const int blocks = (int)(cdiv(pixels, 4) < 8192 ? cdiv(pixels, 4) : 8192);
-    hipLaunchKernelGGL(l2norm_kernel, dim3(blocks), dim3(256), 0, st, in, pixels, C, gamma, out);
+    hipLaunchKernelGGL(l2norm_kernel, dim3(blocks), dim3(256), 0, st, in, pixels, C, gamma, out, planes, plane, np);
     SSD_LAUNCH_CHECK();
     return SSD_OK;
 }

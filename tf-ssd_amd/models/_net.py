@@ -292,6 +292,23 @@ class SSDModel(object):
             raise RuntimeError(lib.ssd_last_error().decode())
         return a
 
+    def fetch_planes(self, name):
+        """The bf16 planes of a named activation of the last forward (what the LDS-DMA conv tiles of its consumers read),
+        joined back to fp32: ``(array, planes)`` with planes 3 (exact split) or 1 (bf16 rounding); ``(None, planes)`` when
+        no running layer asked for them."""
+        lib = _h.lib()
+        npl = ctypes.c_int(0)
+        n = lib.ssd_net_fetch_planes(self._net, name.encode(), None, 0, ctypes.byref(npl))
+        if n < 0:
+            raise ValueError(lib.ssd_last_error().decode())
+        if n == 0:
+            return None, npl.value
+        a = np.empty((n,), np.float32)
+        got = lib.ssd_net_fetch_planes(self._net, name.encode(), a.ctypes.data_as(_h.c_float_p), a.size, ctypes.byref(npl))
+        if got < 0:
+            raise RuntimeError(lib.ssd_last_error().decode())
+        return a, npl.value
+
     def layers(self, B):
         lib = _h.lib()
         out = []

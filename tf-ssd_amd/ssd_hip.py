@@ -119,6 +119,7 @@ _SIGNATURES = {
     "ssd_net_predict": (ctypes.c_int, [vp, vp, ctypes.c_int, vp, c_float_p, ctypes.c_int,
                                        ctypes.c_float, ctypes.c_float, vp, vp, vp, vp, vp]),
     "ssd_net_fetch_activation": (ctypes.c_long, [vp, ctypes.c_char_p, c_float_p, ctypes.c_size_t]),
+    "ssd_net_fetch_planes": (ctypes.c_long, [vp, ctypes.c_char_p, c_float_p, ctypes.c_size_t, c_int_p]),
     "ssd_net_num_layers": (ctypes.c_int, [vp]),
     "ssd_net_layer_name": (ctypes.c_char_p, [vp, ctypes.c_int]),
     "ssd_net_layer_kind": (ctypes.c_char_p, [vp, ctypes.c_int]),
