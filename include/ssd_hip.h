@@ -50,6 +50,9 @@ int ssd_init(int device);
  * the NULL stream on this stack: recording the per-step dependency there serialised the lanes, measured.)
  * high_priority != 0: the device's greatest stream priority.  Returns NULL on failure (ssd_last_error). */
 void* ssd_stream_create(int high_priority);
+/* ... restricted to the compute units whose bits are set in cu_mask[0 .. words) (hipExtStreamCreateWithCUMask): lanes on
+ * DISJOINT sets of XCDs run truly concurrently, each with a whole number of workgroup rounds of its own. */
+void* ssd_stream_create_masked(const unsigned* cu_mask, int words);
 int ssd_stream_destroy(void* stream);
 
 /* ---- prior boxes: utils/bbox_utils.py:115-176 (A1-A3) ------------------------------

@@ -130,8 +130,23 @@ class DecoderModel(object):
                 m.set_option("lanes_hint", self.lanes)
             self._lane_models.append(m)
             if len(self._lane_streams) < len(self._lane_models):
-                self._lane_streams.append(_h.new_stream())
+                self._lane_streams.append(self._new_lane_stream(len(self._lane_streams)))
         return self._lane_models[i], self._lane_streams[i]
+
+    def _new_lane_stream(self, i):
+        """Lane i's stream.  SSD_HIP_LANE_CUMASK=div|mod (experiment): the lane is confined to its own
+        1/lanes of the compute units -- ``div``: CU bits [i * 256 / lanes, (i + 1) * 256 / lanes); ``mod``: bits b with
+        b % lanes == i -- so the lanes run side by side instead of taking turns on the whole chip."""
+        import os
+        mode = os.environ.get("SSD_HIP_LANE_CUMASK", "")
+        if mode not in ("div", "mod") or self.lanes < 2:
+            return _h.new_stream()
+        n = self.lanes
+        if mode == "div":
+            bits = [b for b in range(256) if b * n // 256 == i]
+        else:
+            bits = [b for b in range(256) if b % n == i]
+        return _h.new_masked_stream(bits)
 
     def _calibrate_lane_streams(self, x):
         """Which PAIR of streams the two lanes run on decides whether their kernels really execute

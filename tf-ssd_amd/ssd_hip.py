@@ -109,6 +109,7 @@ _SIGNATURES = {
     "ssd_net_tuning_stats": (ctypes.c_int, [vp, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int)]),
     "ssd_build_id": (ctypes.c_char_p, []),
     "ssd_stream_create": (vp, [ctypes.c_int]),
+    "ssd_stream_create_masked": (vp, [ctypes.POINTER(ctypes.c_uint), ctypes.c_int]),
     "ssd_stream_destroy": (ctypes.c_int, [vp]),
     "ssd_net_regularization_loss": (ctypes.c_int, [vp, c_float_p]),
     "ssd_net_train_set_buckets": (ctypes.c_int, [vp, ctypes.c_int, ctypes.POINTER(ctypes.c_long)]),
@@ -214,6 +215,22 @@ def new_stream(high_priority=False):
         raise SsdHipError("ssd_stream_create: %s" % lib().ssd_last_error().decode())
     st = torch.cuda.ExternalStream(h)
     st._ssd_high_priority = hp
+    return st
+
+
+def new_masked_stream(cu_bits):
+    """A native stream restricted to the compute units in ``cu_bits`` (iterable of CU bit indices of
+    ``hipExtStreamCreateWithCUMask``).  Not pooled (the mask is part of the stream); never destroyed, like the others."""
+    device()
+    words = [0] * 8
+    for b in cu_bits:
+        words[b // 32] |= 1 << (b % 32)
+    arr = (ctypes.c_uint * 8)(*words)
+    hnd = lib().ssd_stream_create_masked(arr, 8)
+    if not hnd:
+        raise SsdHipError("ssd_stream_create_masked: %s" % lib().ssd_last_error().decode())
+    st = torch.cuda.ExternalStream(hnd)
+    st._ssd_high_priority = None
     return st
 
 
