@@ -250,6 +250,9 @@ const ConvDCfg kCfgD[] = {
     DCFG(2, 7, 4, 1),    // 128 x 112, 4 waves
     DCFG(2, 5, 2, 2),    // 64 x 160, 4 waves
     DCFG(2, 4, 6, 2),    // 192 x 128, 12 waves
+    DCFG(3, 4, 4, 3),    // 192 x 192, 12 waves
+    DCFG(2, 4, 8, 2),    // 256 x 128, 16 waves
+    DCFG(2, 2, 2, 2),    // 64 x 64, 4 waves
 };
 constexpr int kNumCfgD = sizeof(kCfgD) / sizeof(kCfgD[0]);
 
