@@ -120,6 +120,23 @@ int ssd_match_encode(const float* priors_dev, const float* gt_boxes_dev,
 int ssd_preprocess(const unsigned char* image_u8_dev, int B, int H, int W, int C, int out_h, int out_w,
                    float* out_dev, void* stream);
 
+/* ---- augmentation: augmentation.py:4-183 (used at trainer.py:42), the deterministic pieces; the random draws of the
+ * reference's tf.random.uniform / sample_distorted_bounding_box calls are INPUTS (host side: tf-ssd_amd/augmentation.py).
+ * Images float32 [B,H,W,C] in [0,1] (the reference augments after convert + resize).
+ * ssd_image_mean: mean_out[b][c] = mean over H, W of (img + add[b]) (add NULL = 0): expand_image's fill colour
+ *   (augmentation.py:142) and adjust_contrast's pivot.
+ * ssd_augment_geometry: params [B][10] int32 = {canvas_h, canvas_w, pad_top, pad_left, crop_y, crop_x, crop_h, crop_w,
+ *   flip, use_crop}: expand_image (:123-151) as a virtual canvas filled with fill[b][c], patch's tf.slice + tf.image.resize
+ *   to out_h x out_w (:176-177, bilinear, half-pixel centres), flip_horizontally (:106) -- one gather kernel, out != img;
+ *   use_crop 0 (flip only) needs out_h x out_w == H x W; the whole canvas as the window at its own size materialises it.
+ * ssd_augment_color (C = 3, in place): params [B][4] = {brightness delta, contrast factor, hue delta, saturation factor},
+ *   flags [B] bits 0..3 = which run (:51-93, reference order), mean [B][3] = contrast's pivot; ends with clip [0,1] (:27). */
+int ssd_image_mean(const float* img_dev, int B, int H, int W, int C, const float* add_dev, float* mean_out_dev, void* stream);
+int ssd_augment_geometry(const float* img_dev, int B, int H, int W, int C, int out_h, int out_w, const int* params_dev,
+                         const float* fill_dev, float* out_dev, void* stream);
+int ssd_augment_color(float* img_dev, int B, int H, int W, const float* params_dev, const int* flags_dev,
+                      const float* mean_dev, void* stream);
+
 /* ---- training loss: ssd_loss.py:8-65 (N1) ----------------------------------------------
  * CustomLoss.loc_loss_fn + conf_loss_fn in one kernel per image.
  *   actual_deltas / pred_deltas [B,N,4]; actual_labels (one-hot) / pred_labels (probabilities)

@@ -413,6 +413,7 @@ def test_trainer_entry_point_fit(tmp_path, monkeypatch, capsys):
     monkeypatch.setenv("SSD_TRAINER_EPOCHS", "2")
     monkeypatch.setenv("SSD_TRAINER_STEPS", "3")
     monkeypatch.setenv("SSD_TRAINER_BATCH", "4")
+    monkeypatch.setenv("SSD_TRAINER_AUGMENT", "0")        # (the loss comparison below wants the same batches in both epochs)
     trainer = importlib.import_module("trainer")
     hist = trainer.main(["--backbone", "mobilenet_v2"])
     out = capsys.readouterr().out

@@ -69,6 +69,9 @@ _SIGNATURES = {
     "ssd_match_encode": (ctypes.c_int, [vp, vp, vp, c_float_p, ctypes.c_float] + [ctypes.c_int] * 4 +
                          [vp, vp, vp, vp, vp]),
     "ssd_preprocess": (ctypes.c_int, [vp] + [ctypes.c_int] * 6 + [vp, vp]),
+    "ssd_image_mean": (ctypes.c_int, [vp] + [ctypes.c_int] * 4 + [vp, vp, vp]),
+    "ssd_augment_geometry": (ctypes.c_int, [vp] + [ctypes.c_int] * 6 + [vp, vp, vp, vp]),
+    "ssd_augment_color": (ctypes.c_int, [vp] + [ctypes.c_int] * 3 + [vp, vp, vp, vp]),
     "ssd_loss_workspace_bytes": (ctypes.c_size_t, [ctypes.c_int, ctypes.c_int]),
     "ssd_loss": (ctypes.c_int, [vp, vp, vp, vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_float,
                                 ctypes.c_float, vp, vp, vp, vp, vp, vp, ctypes.c_float, vp, ctypes.c_size_t, vp]),

@@ -105,6 +105,12 @@ def main(argv=None):
         ssd_model.load_weights(ssd_model_path)
     ssd_log_path = io_utils.get_log_path(backbone)
     prior_boxes = bbox_utils.generate_prior_boxes(hyper_params["feature_map_shapes"], hyper_params["aspect_ratios"])
+    # reference trainer.py:42: the TRAINING stream is augmented (fresh draws every epoch), the validation stream is not.
+    # SSD_TRAINER_AUGMENT=0 turns it off (deterministic smoke runs).
+    if os.environ.get("SSD_TRAINER_AUGMENT", "1") != "0":
+        import augmentation
+        augmentation.seed(4242 + rank)
+        train_data = augmentation.augmented(train_data)
     ssd_train_feed = train_utils.generator(train_data, prior_boxes, hyper_params)
     ssd_val_feed = train_utils.generator(val_data, prior_boxes, hyper_params)
 
