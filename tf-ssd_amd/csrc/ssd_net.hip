@@ -757,8 +757,10 @@ ssd_net* ssd_net_create(int backbone, int img_size, int levels, const int* n_ars
     // hipGraph capture / replay of a step (forks onto the side streams) segfaults inside the HIP runtime when it is
     // limited to fewer than four hardware queues (GPU_MAX_HW_QUEUES=2, the two-lane serving setup: measured on
     // ROCm 7.2): such processes launch directly, which is also what the launch-mode race picks at B >= 64
+    // (SSD_HIP_GRAPH_FORCE=1: diagnostics -- tests/micro/graph_queues_net.py looks for what exactly crashes)
+    const bool graph_force = getenv("SSD_HIP_GRAPH_FORCE") && atoi(getenv("SSD_HIP_GRAPH_FORCE")) != 0;
     if (const char* q = getenv("GPU_MAX_HW_QUEUES"))
-        if (atoi(q) > 0 && atoi(q) < 4) {
+        if (atoi(q) > 0 && atoi(q) < 4 && !graph_force) {
             net->use_graph = false;
             net->use_graph_auto = false;
             net->graphs_unsafe = true;

@@ -441,7 +441,7 @@ class SSDModel(object):
             return parallel.allreduce_gradients_as_ready(
                 g, self._bucket_starts,
                 wait_bucket=lambda k, st: _h.check(lib.ssd_net_train_wait_bucket(self._net, k, _h.vp(st.cuda_stream)), "wait_bucket"),
-                comm_stream=None if os.environ.get("SSD_HIP_COMM_STREAM", "1") == "0" else self._comm_stream)
+                comm_stream=self._comm_stream)
         return parallel.allreduce_gradients(g)
 
     def _plan_gradient_buckets(self, batch, n_buckets):
