@@ -507,13 +507,26 @@ def train_bench(args, hp, get_model, rank, world, dist):
     gt, gl = data_utils.synthetic_gt(B, total_labels=hp["total_labels"], seed=3 + rank)
     gt, gl = ssd_hip.to_dev(gt), ssd_hip.to_dev(gl, torch.int32)
 
-    def step():
+    # the step's stream: a native NON-BLOCKING stream when a process group is alive (SSD_BENCH_TRAIN_STREAM=null keeps
+    # torch's legacy NULL stream) -- the NULL stream synchronises implicitly with every blocking stream of the process,
+    # RCCL's among them
+    own_stream = None
+    if os.environ.get("SSD_BENCH_TRAIN_STREAM", "native" if dist is not None else "null") == "native":
+        own_stream = ssd_hip.new_stream()
+
+    def step_body():
         yd, yl = train_utils.calculate_actual_outputs(priors, gt, gl, hp)
         model.plan_gradient_exchange(B)                 # N > 1 (or --force-dist): gradient buckets exchanged as the backward finishes them
         loc, conf, g = model.forward_backward(x, yd, yl)
         w = model.exchange_gradients(g)
         model.apply_gradients(g, 1e-3, 1.0 / w)
         return loc, conf
+
+    def step():
+        if own_stream is None:
+            return step_body()
+        with torch.cuda.stream(own_stream):
+            return step_body()
 
     for _ in range(max(args.warmup, 1)):
         loc, conf = step()

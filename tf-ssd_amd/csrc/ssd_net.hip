@@ -682,6 +682,10 @@ static int autotune(ssd_net& net, int B, hipStream_t st) {
 template <typename F>
 static int run_graphed(ssd_net* net, std::vector<const void*> key, hipStream_t& st, F body) {
     if (!net->use_graph || net->timing) return body();
+    // fewer than four hardware queues: capturing the FORKED step (head convs / tail on side streams) segfaults inside the
+    // runtime (tests/micro/graph_queues_net.py: 2 queues always, 3 queues on a native stream); the single in-order stream
+    // of a lane captures and replays fine at any queue count
+    if (net->graphs_unsafe && net->overlap_heads) return body();
     const hipStream_t caller = st;
     if (st == nullptr) {
         if (!net->gstream && hipStreamCreateWithFlags(&net->gstream, hipStreamDefault) != hipSuccess) {
@@ -1583,8 +1587,8 @@ int ssd_net_set_option(ssd_net* net, const char* name, int value) {
         return SSD_OK;
     }
     if (std::string(name) == "use_graph") {
-        if (value && net->graphs_unsafe) {
-            set_error("ssd_net_set_option: use_graph 1 is not available with GPU_MAX_HW_QUEUES < 4 (hipGraph replay of the forked step crashes in the runtime)");
+        if (value && net->graphs_unsafe && net->overlap_heads) {
+            set_error("ssd_net_set_option: use_graph 1 needs overlap_heads 0 with GPU_MAX_HW_QUEUES < 4 (hipGraph capture of the forked step crashes in the runtime; a single in-order stream replays fine)");
             return SSD_E_UNSUPPORTED;
         }
         net->use_graph = value != 0;

@@ -128,6 +128,9 @@ class DecoderModel(object):
                 # the other lanes fill the chip: whole-image blocks split their channels over fewer workgroups
                 # (B=64, three lanes: 2 groups instead of 4 -> half the slab traffic, 44.5 k -> 47.0 k images/sec)
                 m.set_option("lanes_hint", self.lanes)
+                import os
+                if os.environ.get("SSD_HIP_LANE_GRAPH") == "1":    # experiment: a lane is one in-order stream -- its step replays as a hipGraph at any queue count
+                    m.set_option("use_graph", 1)
             self._lane_models.append(m)
             if len(self._lane_streams) < len(self._lane_models):
                 self._lane_streams.append(self._new_lane_stream(len(self._lane_streams)))
