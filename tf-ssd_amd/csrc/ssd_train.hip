@@ -884,7 +884,7 @@ struct ssd_train_state {
     float* partial_w = nullptr;
     size_t partial_w_floats = 0;
     hipStream_t wstream = nullptr;
-    hipEvent_t ev_dy = nullptr, ev_wdone[2] = {nullptr, nullptr}, ev_wall = nullptr;
+    hipEvent_t ev_dy = nullptr, ev_wdone[2] = {nullptr, nullptr}, ev_wall = nullptr, ev_main_pos = nullptr;
     bool wpending[2] = {false, false};
     float* pack_jobs = nullptr;  // device array of PackJob (one launch re-packs every conv weight)
     int n_pack_jobs = 0;
@@ -907,7 +907,7 @@ void ssd_train_state_free(ssd_train_state* s) {
     for (auto e : s->bucket_ev)
         if (e) (void)hipEventDestroy(e);
     if (s->wstream) { (void)hipStreamSynchronize(s->wstream); (void)hipStreamDestroy(s->wstream); }
-    for (hipEvent_t e : {s->ev_dy, s->ev_wdone[0], s->ev_wdone[1], s->ev_wall})
+    for (hipEvent_t e : {s->ev_dy, s->ev_wdone[0], s->ev_wdone[1], s->ev_wall, s->ev_main_pos})
         if (e) (void)hipEventDestroy(e);
     for (float* p : s->owned)
         if (p) (void)hipFree(p);
@@ -1377,7 +1377,8 @@ int ssd_net_train_begin(ssd_net* net, int batch) {
             hipEventCreateWithFlags(&s->ev_dy, hipEventDisableTiming) != hipSuccess ||
             hipEventCreateWithFlags(&s->ev_wdone[0], hipEventDisableTiming) != hipSuccess ||
             hipEventCreateWithFlags(&s->ev_wdone[1], hipEventDisableTiming) != hipSuccess ||
-            hipEventCreateWithFlags(&s->ev_wall, hipEventDisableTiming) != hipSuccess) {
+            hipEventCreateWithFlags(&s->ev_wall, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&s->ev_main_pos, hipEventDisableTiming) != hipSuccess) {
             (void)hipGetLastError();
             set_error("ssd_net_train_begin: side stream / events for the weight gradients could not be created");
             rc = SSD_E_HIP;
@@ -1567,16 +1568,30 @@ int ssd_net_train_forward_backward(ssd_net* net, const float* image_dev, int B, 
         s.wpending[0] = s.wpending[1] = false;
         return SSD_OK;
     };
+    // A bucket is final when BOTH streams have passed this point: the main stream (BatchNorm / depthwise / bias gradients,
+    // the data-gradient chain) and the side stream (the dense convs' weight gradients).  The bucket's event is recorded on
+    // the SIDE stream behind a wait for the main stream's position -- the main stream itself never waits (round 4 joined the
+    // side stream INTO the main stream here and therefore ran the weight gradients in line under buckets: +0.9 ms per step).
+    static const bool wside_buckets = !getenv("SSD_HIP_WGRAD_SIDE_BUCKETS") || atoi(getenv("SSD_HIP_WGRAD_SIDE_BUCKETS")) != 0;
     auto mark_ready = [&](long threshold) -> int {
         bool joined = false;
         while (next_bucket > 0 && s.bucket_lo[next_bucket - 1] >= threshold) {
-            if (!joined) {                   // a bucket is final only when the side stream's weight gradients in it are
-                const int rj = join_wgrads();
-                if (rj) return rj;
-                joined = true;
-            }
             if (getenv("SSD_HIP_DEBUG_BUCKETS")) fprintf(stderr, "[ssd] bucket %zu (lo %ld) final at threshold %ld\n", next_bucket - 1, s.bucket_lo[next_bucket - 1], threshold);
-            SSD_HIP(hipEventRecord(s.bucket_ev[next_bucket - 1], st));
+            if (s.wstream && wside_buckets) {
+                if (!joined) {
+                    SSD_HIP(hipEventRecord(s.ev_main_pos, st));
+                    SSD_HIP(hipStreamWaitEvent(s.wstream, s.ev_main_pos, 0));
+                    joined = true;
+                }
+                SSD_HIP(hipEventRecord(s.bucket_ev[next_bucket - 1], s.wstream));
+            } else {
+                if (!joined) {
+                    const int rj = join_wgrads();
+                    if (rj) return rj;
+                    joined = true;
+                }
+                SSD_HIP(hipEventRecord(s.bucket_ev[next_bucket - 1], st));
+            }
             --next_bucket;
         }
         return SSD_OK;
@@ -1718,7 +1733,7 @@ int ssd_net_train_forward_backward(ssd_net* net, const float* image_dev, int B, 
         // at their gradient bucket: the data-gradient chain below does not wait for them)
         // (not under the bucketed data-parallel exchange: there the communication stream already runs beside the backward,
         // and a third stream measured slower at world size 1 -- 12.6 against 11.5 ms -- than the weight gradients in line)
-        const bool side = s.wstream && s.bucket_lo.empty();
+        const bool side = s.wstream && (s.bucket_lo.empty() || wside_buckets);
         hipStream_t wst = side ? s.wstream : st;
         if (side) {
             SSD_HIP(hipEventRecord(s.ev_dy, st));
