@@ -469,6 +469,7 @@ def test_bench_line_contract(extra, tmp_path):
     import json, subprocess, sys
     repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, SSD_HIP_TUNE_CACHE=str(tmp_path))
+    env.pop("GPU_MAX_HW_QUEUES", None)          # (the suite pins the runtime's default in conftest; bench.py chooses its own: one queue per lane)
     cmd = [sys.executable, os.path.join(repo, "bench.py"), "--steps", "4", "--warmup", "2", "--batch", "8", "--no-cpu-baseline"] + extra
     out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stderr[-2000:]
