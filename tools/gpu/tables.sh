@@ -1,6 +1,6 @@
 #!/bin/bash
 # re-measure every shipped kernel-choice table at the current build (fp32 + bf16 keys)
-OUT=gpurun_out/tables_r4
+OUT=gpurun_out/tables_r5
 rm -rf $OUT; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 ( time SSD_HIP_IGNORE_SHIPPED=1 SSD_HIP_WARN_STALE_TABLE=0 python tools/make_tuning_tables.py --out $OUT --repeats 3 ) > $OUT/log.txt 2>&1
