@@ -369,7 +369,7 @@ def main():
     if os.path.exists(tpath) and hp["img_size"] == 300:
         try:
             fams = json.load(open(tpath))["families"]
-            fam_names = [k for k in ("conv_mfma_kernel", "conv_mfma3_kernel", "conv_wino_kernel", "conv_skinny_kernel") if k in fams]
+            fam_names = [k for k in ("conv_mfma_kernel", "conv_mfma3_kernel", "conv_bf16_kernel", "conv_dma_kernel", "conv_wino_kernel", "conv_skinny_kernel") if k in fams]
             nl = sum(fams[k]["FETCH_SIZE"]["launches"] for k in fam_names)
             # launch-weighted mean over the family's kernels (implicit-GEMM + Winograd tiles)
             fetch = 2.0 * 1024.0 * sum(fams[k]["FETCH_SIZE"]["KB_per_launch_reported"] * fams[k]["FETCH_SIZE"]["launches"]
@@ -427,7 +427,8 @@ def main():
                    # include/ssd_hip.h + the compile flags): equal = the library was built from these sources
                    "build_id_from_sources": build_id_from_sources()},
         "roofline": {"bound": "mfma", "kernel": "conv_mfma3_kernel (implicit-GEMM tiles, every fp32 product as six v_mfma_f32_16x16x32_bf16 of an exact "
-                                                 "3-way operand split) + conv_mfma_kernel / conv_wino_kernel / conv_skinny_kernel (fp32 v_mfma_f32_16x16x4: "
+                                                 "3-way operand split; conv_dma_kernel: the same tiles with both operands copied global -> LDS by LDS-DMA from pre-split / bf16 planes) "
+                                                 "+ conv_mfma_kernel / conv_wino_kernel / conv_skinny_kernel (fp32 v_mfma_f32_16x16x4: "
                                                  "implicit-GEMM, Winograd F(2x2,3x3), in-workgroup-split-K tiles), all configs",
                      # `achieved` / `frac` count the FLOPs the matrix cores actually ISSUED (Winograd layers: 16
                      # multiplies per 2x2 output tile instead of 36, whole border tiles) over the hipEvent time of

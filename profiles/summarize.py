@@ -45,7 +45,7 @@ if trace and os.path.dirname(trace) == os.path.dirname(stats):
     by = defaultdict(lambda: [0, 0.0])
     for r in csv.DictReader(open(trace)):
         n = short(r["Kernel_Name"])
-        if not n.startswith(("conv_mfma3_kernel", "conv_mfma_kernel", "conv_bf16_kernel", "conv_wino_kernel", "(anonymous namespace)::conv_skinny_kernel")):
+        if not n.startswith(("conv_mfma3_kernel", "conv_mfma_kernel", "conv_bf16_kernel", "conv_dma_kernel", "conv_wino_kernel", "(anonymous namespace)::conv_skinny_kernel")):
             continue
         wg = int(r["Workgroup_Size_X"])
         key = (n, "%d x %d workgroups of %d" % (int(r["Grid_Size_X"]) // wg, int(r["Grid_Size_Y"]), wg))

@@ -3,7 +3,7 @@
 # bench lines of every BASELINE configuration that fits one GPU (fp32 and the bf16 mode), per-layer tables, forced
 # single-rank collectives, rocprofv3 kernel stats, PMC traffic + SQ counters of the headline configuration.
 # Summaries land in gpurun_out/<tag>/; profiles/adopt.sh copies them into profiles/.
-TAG=${1:-r4}
+TAG=${1:-r5}
 OUT=gpurun_out/$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
