@@ -630,9 +630,10 @@ def ranks_report(dist, local_region_s, steps):
     over RCCL -- it equals n_gpus only if every rank took part -- and the spread of the per-rank median region time
     (the headline takes the MAX over ranks of every region)."""
     import torch
-    ones = torch.ones(1, dtype=torch.float64, device="cuda")
+    dev = "cuda" if dist.get_backend() == "nccl" else "cpu"          # (gloo: the world-size-2 CPU test)
+    ones = torch.ones(1, dtype=torch.float64, device=dev)
     dist.all_reduce(ones, op=dist.ReduceOp.SUM)
-    lo = torch.tensor([local_region_s], dtype=torch.float64, device="cuda")
+    lo = torch.tensor([local_region_s], dtype=torch.float64, device=dev)
     hi = lo.clone()
     dist.all_reduce(lo, op=dist.ReduceOp.MIN)
     dist.all_reduce(hi, op=dist.ReduceOp.MAX)

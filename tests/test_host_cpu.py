@@ -420,3 +420,68 @@ def test_default_serving_setup_is_placed_before_the_runtime_starts():
     assert run(dict(base, GPU_MAX_HW_QUEUES="8")) == ["8", "1"]             # the process chose: left alone
     assert run(dict(base, GPU_MAX_HW_QUEUES="2")) == ["2", "2"]
     assert run(dict(base, SSD_HIP_HW_QUEUES="runtime")) == ["None", "1"]    # opt-out: the runtime's own default
+
+
+_RANKS_WORKER = '''
+import os, sys
+sys.path[:0] = [%(repo)r]
+import torch.distributed as dist
+dist.init_process_group("gloo")
+import bench
+rep = bench.ranks_report(dist, 0.010 * (1 + dist.get_rank()), 10)
+assert rep["ranks_seen"] == 2 and rep["world_size"] == 2 and rep["backend"] == "gloo", rep
+assert abs(rep["ms_per_step_rank_min"] - 1.0) < 1e-9 and abs(rep["ms_per_step_rank_max"] - 2.0) < 1e-9, rep
+print("rank %%d ok" %% dist.get_rank(), flush=True)
+dist.destroy_process_group()
+'''
+
+
+def test_two_process_gloo_ranks_report(tmp_path):
+    """N > 1 bench lines state what the collective saw: `ranks_seen` (an all-reduce of ones) and the per-rank spread of the
+    step time -- with world size 2 over gloo here, over RCCL on a multi-GPU node."""
+    script = tmp_path / "ranks_worker.py"
+    script.write_text(_RANKS_WORKER % {"repo": REPO})
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                          "--master-addr", "127.0.0.1", "--master-port", str(port), str(script)],
+                         env=dict(os.environ, MASTER_ADDR="127.0.0.1"), capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "rank 0 ok" in out.stdout and "rank 1 ok" in out.stdout
+
+
+def test_augmentation_host_logic_vs_oracle():
+    """The host side of ``tf-ssd_amd/augmentation.py`` (draws -> integer geometry, box arithmetic, the sampler's acceptance
+    rule) against oracle/augment_oracle.py, without a device: bit-exact float32 box math for random draws, the sampler's
+    windows valid and accepted by the ORACLE's rule."""
+    import augmentation as aug
+    from oracle import augment_oracle as ao
+    rng = np.random.default_rng(0)
+    for _ in range(200):
+        h, w = int(rng.integers(8, 400)), int(rng.integers(8, 400))
+        draws = (rng.uniform(1.0, 4.0), rng.random(), rng.random())
+        assert aug.expand_geometry(h, w, *draws) == ao.expand_geometry(h, w, *draws)
+        n = int(rng.integers(1, 6))
+        c, s = rng.uniform(0.1, 0.9, (n, 2)), rng.uniform(0.02, 0.4, (n, 2))
+        g = np.clip(np.concatenate([c - s, c + s], 1), 0, 1).astype(np.float32)
+        fh, fw, pt, pl = aug.expand_geometry(h, w, *draws)
+        _, og, _ = ao.expand_image(np.zeros((h, w, 3), np.float32), g, *draws)
+        np.testing.assert_array_equal(aug.expand_boxes(g, h, w, fh, fw, pt, pl), og)
+        np.testing.assert_array_equal(aug.flip_boxes(g), ao.flip_horizontally(np.zeros((2, 2, 3), np.float32), g)[1])
+        mm = np.sort(rng.random(4).astype(np.float32).reshape(2, 2), 0).reshape(4)
+        if mm[2] > mm[0] and mm[3] > mm[1]:
+            np.testing.assert_array_equal(aug.renormalize(g, mm), ao.renormalize_bboxes_with_min_max(g, mm))
+    aug.seed(3)
+    g = np.array([[0.2, 0.3, 0.6, 0.7], [0.5, 0.1, 0.9, 0.4]], np.float32)
+    for mo in (0.1, 0.3, 0.5, 0.7, 0.9):
+        for _ in range(30):
+            y, x, hh, ww = aug.sample_distorted_bounding_box(200, 300, g, mo)
+            assert 0 <= y and 0 <= x and 0 < hh and 0 < ww and y + hh <= 200 and x + ww <= 300
+            win = np.array([y / 200, x / 300, (y + hh) / 200, (x + ww) / 300])
+            assert (y, x, hh, ww) == (0, 0, 200, 300) or ao.satisfies_overlap(win, g, mo)
+    aug.seed(1)
+    a = [aug.get_random_bool() for _ in range(400)]
+    assert 120 < sum(a) < 280
+    assert {float(aug.get_random_min_overlap()) for _ in range(200)} == {float(np.float32(v)) for v in (0.1, 0.3, 0.5, 0.7, 0.9)}
