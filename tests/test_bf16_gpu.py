@@ -130,7 +130,7 @@ def test_bf16_forward_vs_fp32_oracle(backbone, B, S, subset):
     d32, p32 = [_np(t) for t in m32(x)]
     d16, p16 = [_np(t) for t in m16(x)]
     kinds = {r["config"].split("_")[0] for r in m16.layers(B) if r["flops"] > 0 and r["config"]}
-    assert "bf16" in kinds, "no layer of the bf16 net runs a bf16 tile: %s" % sorted(kinds)
+    assert kinds & {"bf16", "dmab"}, "no layer of the bf16 net runs a bf16 tile (register-staged bf16_* or LDS-DMA dmab_*): %s" % sorted(kinds)
     assert np.isfinite(d16).all() and np.isfinite(p16).all()
     np.testing.assert_allclose(p16.sum(-1), 1.0, atol=1e-5)
     var = np.asarray(hp["variances"], np.float32)
