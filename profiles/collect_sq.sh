@@ -7,7 +7,7 @@ cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 export SSD_HIP_TUNE_CACHE=$OUT/tune
 # one step at a time, no intra-step side streams, no second timing leg: every kernel runs alone, so the per-kernel
 # averages of the trace are uncontended and reproduce the bench line's per-layer hipEvent times
-CMD="python bench.py --steps 10 --warmup 3 --no-cpu-baseline --lanes 1 --no-overlap --no-other-leg --no-h2d"
+CMD="python bench.py --steps 10 --warmup 3 --no-cpu-baseline --lanes 1 --no-overlap --no-other-leg --no-h2d $BENCH_ARGS"
 timeout 600 $CMD > $OUT/bench_plain.log 2>&1
 timeout 900 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_INSTS_VALU_MFMA_MOPS_F32 --kernel-trace --output-format csv -d $OUT/sq -o s -- $CMD > $OUT/bench_sq.log 2>&1
 tail -3 $OUT/bench_sq.log | cut -c1-200
