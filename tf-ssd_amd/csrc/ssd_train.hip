@@ -141,10 +141,12 @@ struct PackJob {
 };
 __global__ __launch_bounds__(256) void pack_jobs_kernel(const PackJob* __restrict__ jobs) {
     const PackJob j = jobs[blockIdx.y];
-    const long total = (long)j.Npad * j.Kpad;
+    const int total = j.Npad * j.Kpad;            // < 2^31 (ssd_net_train_begin checks): 32-bit index arithmetic
     const int C2 = j.Cout - j.Cout1;
-    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
-        const int n = (int)(e / j.Kpad), k = (int)(e - (long)n * j.Kpad);
+    // the jobs differ by three orders of magnitude (a 16 x 32 pointwise kernel .. head level 2's 160 x 11 520): every job gets
+    // gridDim.x blocks, the small ones leave at once (16 blocks per job took 309 us of a 10.8 ms step)
+    for (int e = blockIdx.x * 256 + threadIdx.x; e < total; e += gridDim.x * 256) {
+        const int n = e / j.Kpad, k = e - n * j.Kpad;
         float v = 0.f;
         if (j.mode == 0) {
             if (n < j.Cout && k < j.K) v = n < j.Cout1 ? j.w[(long)k * j.Cout1 + n] : j.w2[(long)k * C2 + (n - j.Cout1)];
@@ -162,13 +164,13 @@ __global__ __launch_bounds__(256) void pack_jobs_kernel(const PackJob* __restric
         // (only the planes this precision's tiles read: the re-pack runs every step)
         short* pl = reinterpret_cast<short*>(j.dst + total);
         if (j.bf16) {
-            pl[3 * total + e] = rne1(v);
+            pl[3 * (long)total + e] = rne1(v);
         } else {
             short h, m, l;
             split1(v, h, m, l);
             pl[e] = h;
-            pl[total + e] = m;
-            pl[2 * total + e] = l;
+            pl[(long)total + e] = m;
+            pl[2 * (long)total + e] = l;
         }
     }
 }
@@ -334,10 +336,25 @@ __global__ __launch_bounds__(256) void col_finalize_kernel(const float* __restri
     const int cl = threadIdx.x & 15, kl = threadIdx.x >> 4;
     const int c = blockIdx.x * 16 + cl;
     float s1 = 0.f, s2 = 0.f;
+    // eight chunks' loads in flight per lane before the (in-order) adds: the loop is a chain of L2 round trips otherwise
+    // (256 chunks = 16 trips of ~0.4 us: 6.9 us per launch, 118 launches per MobileNetV2 step)
     if (c < C)
-        for (int k = kl; k < chunks; k += 16) {
-            s1 += partial[(long)k * 2 * C + c];
-            s2 += partial[(long)k * 2 * C + C + c];
+        for (int k0 = kl; k0 < chunks; k0 += 128) {
+            float a[8], b[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int k = k0 + 16 * u;
+                const bool ok = k < chunks;
+                const long o = (long)(ok ? k : 0) * 2 * C + c;
+                a[u] = partial[o];
+                b[u] = partial[o + C];
+                if (!ok) a[u] = b[u] = 0.f;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                s1 += a[u];
+                s2 += b[u];
+            }
         }
     sh[0][kl][cl] = s1;
     sh[1][kl][cl] = s2;
@@ -395,7 +412,17 @@ __global__ __launch_bounds__(256) void chunk_sum4_kernel(const float* __restrict
     const long e = ((long)blockIdx.x * EQ + el) * 4;
     tf32x4 acc = {0.f, 0.f, 0.f, 0.f};
     if (e < n)
-        for (int k = kl; k < chunks; k += KL) acc += *reinterpret_cast<const tf32x4*>(partial + (long)k * n + e);
+        for (int k0 = kl; k0 < chunks; k0 += 8 * KL) {          // eight loads in flight, added in chunk order
+            tf32x4 v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int k = k0 + u * KL;
+                v[u] = *reinterpret_cast<const tf32x4*>(partial + (long)(k < chunks ? k : 0) * n + e);
+                if (k >= chunks) v[u] = tf32x4{0.f, 0.f, 0.f, 0.f};
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) acc += v[u];
+        }
     sh[kl][el] = acc;
     __syncthreads();
     if (kl != 0 || e >= n) return;
@@ -1364,6 +1391,8 @@ int ssd_net_train_begin(ssd_net* net, int batch) {
             jobs.push_back(j);
         }
     }
+    for (const PackJob& j : jobs)
+        SSD_UNSUPPORTED_IF((long)j.Npad * j.Kpad > 0x7fffffffL, "train: a packed weight matrix of %d x %d exceeds 32-bit indexing", j.Npad, j.Kpad);
     s->n_pack_jobs = (int)jobs.size();
     s->precision = net->precision;
     if (!rc && !jobs.empty()) rc = talloc(*s, (jobs.size() * sizeof(PackJob) + 3) / 4, &s->pack_jobs);
@@ -1471,7 +1500,7 @@ int ssd_net_train_forward_backward(ssd_net* net, const float* image_dev, int B, 
 
     // re-pack the (just updated) weights of every conv: forward and backward-data forms, one launch
     if (s.n_pack_jobs) {
-        hipLaunchKernelGGL(pack_jobs_kernel, dim3(16, (unsigned)s.n_pack_jobs), dim3(256), 0, st,
+        hipLaunchKernelGGL(pack_jobs_kernel, dim3(128, (unsigned)s.n_pack_jobs), dim3(256), 0, st,
                            reinterpret_cast<const PackJob*>(s.pack_jobs));
         SSD_LAUNCH_CHECK();
     }

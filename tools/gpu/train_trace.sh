@@ -1,6 +1,6 @@
 #!/bin/bash
 # steady-state kernel trace of the training step (cost-model tile choice: no tuning launches in the trace)
-OUT=gpurun_out/r4u
+OUT=gpurun_out/${TAG:-r5tr}
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 export SSD_HIP_TRAIN_AUTOTUNE=${TUNE:-1}
