@@ -35,4 +35,4 @@ for n, v in fam.most_common(25):
     print("%-40s %7.3f ms/step  %5.0f launches/step  %6.1f us avg" % (n[:40], v / 6e6, cnt[n] / 6, v / cnt[n] / 1e3))
 print("sum of kernel durations %.3f ms/step" % (sum(fam.values()) / 6e6))
 PY
-rm -rf $OUT/trace
+python tools/gpu/wgrad_list.py $OUT/trace > $OUT/last_step_kernels.txt 2>&1; rm -rf $OUT/trace
