@@ -215,11 +215,14 @@ int ssd_conv2d_ex(const ssd_conv_desc* d, const float* in_dev, const float* pack
 /* The same op on the LDS-DMA tiles ("dma3_*" / "dmab_*" configs, csrc/ssd_convdma.hip): the INPUT is handed over as
  * bf16 planes [planes][n] (planes = 3: the exact split x = h + m + l of the fp32 activation, fp32 results as above;
  * planes = 1: its bf16 rounding -- the bf16 mode's storage format), `in_plane_stride` ELEMENTS between planes; both
- * operands then reach LDS by `buffer_load ... lds` without passing through registers.  ssd_split_planes writes such
+ * operands then reach LDS by `buffer_load ... lds` without passing through registers.  Inside a plane the NHWC tensor
+ * of `channels` channels (a multiple of 32) and P = n / channels pixels is stored SLICE-MAJOR, [channels / 32][P][32]:
+ * element (pixel, c) at ((c / 32) * P + pixel) * 32 + c % 32 -- the 16 rows x 64 bytes of one copy instruction are then
+ * 1 KB of contiguous memory.  ssd_split_planes writes such
  * planes from an fp32 tensor (n % 4 == 0), ssd_join_planes restores fp32 (exactly, for planes = 3); the conv can write
- * its own output as planes too (out_planes_dev != NULL: dense outputs with Cout % 4 == 0) for the next layer. */
-int ssd_split_planes(const float* x_dev, long n, int planes, void* planes_dev, long plane_stride, void* stream);
-int ssd_join_planes(const void* planes_dev, long n, int planes, long plane_stride, float* x_dev, void* stream);
+ * its own output as planes too (out_planes_dev != NULL: dense outputs with Cout % 32 == 0) for the next layer. */
+int ssd_split_planes(const float* x_dev, long n, int channels, int planes, void* planes_dev, long plane_stride, void* stream);
+int ssd_join_planes(const void* planes_dev, long n, int channels, int planes, long plane_stride, float* x_dev, void* stream);
 int ssd_conv2d_planes(const ssd_conv_desc* d, const void* in_planes_dev, int planes, long in_plane_stride,
                       const float* packed_w_dev, const float* scale_dev, const float* shift_dev,
                       const float* residual_dev, float* out_dev, long out_batch_stride, long out_pixel_stride,

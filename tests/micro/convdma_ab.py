@@ -57,7 +57,7 @@ for name, b, H, Cin, Cout, k, stride, pads in SHAPES:
     planes = {np_: torch.zeros(np_ * stride_e + 64, dtype=torch.int16, device="cuda") for np_ in (1, 3)}
     split_us = {}
     for np_ in (1, 3):
-        split_us[np_] = timed(lambda: lib.ssd_split_planes(h.ptr(x), n_in, np_, h.ptr(planes[np_]), stride_e, st))
+        split_us[np_] = timed(lambda: lib.ssd_split_planes(h.ptr(x), n_in, Cin, np_, h.ptr(planes[np_]), stride_e, st))
     d = h.ConvDesc(b, H, H, Cin, Cout, k, k, stride, 1, pads[0], pads[2], pads[1], pads[3], 2, 0)
     wino = k == 3 and stride == 1
     if wino:

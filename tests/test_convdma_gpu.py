@@ -27,8 +27,8 @@ POISON = 4096          # bf16 elements of NaN around every plane
 
 
 def make_planes(x, np_):
-    """fp32 array -> (device int16 buffer, byte pointer of plane 0, plane stride in elements): planes written by
-    ``ssd_split_planes`` into a NaN-poisoned buffer (bf16 NaN = 0x7fc0)."""
+    """fp32 NHWC array (last axis = channels, a multiple of 32) -> (device int16 buffer, byte pointer of plane 0, plane
+    stride in elements): slice-major planes written by ``ssd_split_planes`` into a NaN-poisoned buffer (bf16 NaN = 0x7fc0)."""
     import ssd_hip as h
     lib = h.lib()
     xd = guarded(x)
@@ -37,14 +37,18 @@ def make_planes(x, np_):
     buf = torch.full((POISON + np_ * stride + POISON,), 0x7fc0, dtype=torch.int16, device=xd.device)
     p0 = buf.data_ptr() + 2 * POISON
     assert p0 % 16 == 0
-    h.check(lib.ssd_split_planes(h.ptr(xd), n, np_, h.vp(p0), stride, h.stream()), "split_planes")
+    rc = lib.ssd_split_planes(h.ptr(xd), n, int(x.shape[-1]), np_, h.vp(p0), stride, h.stream())
+    if x.shape[-1] % 32:            # no slice-major planes of such a tensor: refused, the buffer stays poison
+        assert rc == -1 and b"channels" in lib.ssd_last_error()
+    else:
+        h.check(rc, "split_planes")
     return buf, p0, stride
 
 
-def join_planes(p0, n, np_, stride):
+def join_planes(p0, n, channels, np_, stride):
     import ssd_hip as h
     out = torch.empty((n,), dtype=torch.float32, device=h.device())
-    h.check(h.lib().ssd_join_planes(h.vp(p0), n, np_, stride, h.ptr(out), h.stream()), "join_planes")
+    h.check(h.lib().ssd_join_planes(h.vp(p0), n, channels, np_, stride, h.ptr(out), h.stream()), "join_planes")
     return _np(out)
 
 
@@ -70,7 +74,7 @@ def run_conv_planes(x, w, np_, cfg, scale=None, shift=None, res=None, stride=1, 
     n_out = B * Ho * Wo * Cout
     op = None
     ostride = 0
-    if want_planes and Cout % 4 == 0:
+    if want_planes and Cout % 32 == 0:
         ostride = (n_out + 63) // 64 * 64
         op = torch.full((np_ * ostride + 64,), 0x7fc0, dtype=torch.int16, device=wd.device)
     ws = torch.empty(max(1, split_k * n_out), dtype=torch.float32, device=wd.device) if split_k > 1 else None
@@ -78,7 +82,7 @@ def run_conv_planes(x, w, np_, cfg, scale=None, shift=None, res=None, stride=1, 
                                h.ptr(out), 0, 0, h.ptr(op), ostride, cfg, split_k, h.ptr(ws), h.stream())
     joined = None
     if rc == 0 and op is not None:
-        joined = join_planes(op.data_ptr(), n_out, np_, ostride).reshape(B, Ho, Wo, Cout)
+        joined = join_planes(op.data_ptr(), n_out, Cout, np_, ostride).reshape(B, Ho, Wo, Cout)
     return rc, out, joined
 
 
@@ -91,19 +95,22 @@ def dma_configs(prefix):
 
 def test_split_planes_is_exact_and_join_restores_it():
     rng = np.random.default_rng(3)
-    x = (rng.standard_normal(8192) * np.exp(rng.uniform(-30, 30, 8192))).astype(np.float32)
+    x = (rng.standard_normal(8192) * np.exp(rng.uniform(-30, 30, 8192))).astype(np.float32)        # 128 pixels x 64 channels
     x[:8] = [0.0, -0.0, 1.0, -1.0, 3.0e38, -3.0e38, 1e-30, 6.0]
     x[8:12] = np.float32([2.0 ** -120, -(2.0 ** -120), 1.17549435e-38, 65504.0])
-    buf, p0, stride = make_planes(x, 3)
-    back = join_planes(p0, x.size, 3, stride)
+    buf, p0, stride = make_planes(x.reshape(128, 64), 3)
+    back = join_planes(p0, x.size, 64, 3, stride)
     big = np.abs(x) >= np.float32(2.0 ** -100)           # below ~2^-110 the l plane leaves bf16's normal range (documented)
     np.testing.assert_array_equal(back[big].view(np.uint32), x[big].view(np.uint32))
     assert np.abs(back[~big] - x[~big]).max() <= np.float32(2.0 ** -125)
     # the poison around the planes is untouched
     allb = _np(buf)
     assert (allb[:POISON] == 0x7fc0).all() and (allb[POISON + x.size:POISON + stride] == 0x7fc0).all()
-    buf1, p1, stride1 = make_planes(x, 1)
-    np.testing.assert_array_equal(join_planes(p1, x.size, 1, stride1), bf16_round(x))
+    buf1, p1, stride1 = make_planes(x.reshape(128, 64), 1)
+    np.testing.assert_array_equal(join_planes(p1, x.size, 64, 1, stride1), bf16_round(x))
+    # slice-major: plane h of channel slice 1 starts P * 32 elements in -- pixel 5, channel 40 sits at (1 * 128 + 5) * 32 + 8
+    h_plane = allb[POISON:POISON + x.size].view(np.uint16)
+    assert h_plane[(128 + 5) * 32 + 8] == (x.reshape(128, 64)[5, 40].view(np.uint32) >> 16)
 
 
 DMA_CASES = [

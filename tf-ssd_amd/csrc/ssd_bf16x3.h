@@ -118,9 +118,18 @@ __device__ __forceinline__ void pack_planes(float x, int bf16_mode, short& h, sh
 }
 
 // The activation as bf16 PLANES for the LDS-DMA tiles of its consumers (ssd_convdma.hip): np = 3 the exact split
-// x = h + m + l (planes h, m, l), np = 1 the bf16 rounding; layout [np][elements] with `plane` elements between planes.
+// x = h + m + l (planes h, m, l), np = 1 the bf16 rounding; `plane` elements between planes.  Inside a plane the layout is
+// SLICE-MAJOR, [C / 32][P pixels][32 channels]: the 16 tile rows x 64 bytes one LDS-DMA wave-instruction copies are 1 KB of
+// CONTIGUOUS memory for consecutive pixels (a [pixel][C] plane makes them 16 half-used 128-byte lines C * 2 bytes apart:
+// tests/micro/lds_dma_rate.hip measures 35 - 48 GB/s per workgroup for that against 50 - 67 contiguous, and the conv tiles
+// gained 12 - 19 %).  The packed weights' planes use the same scheme, [Kpad / 32][Npad][32] (plane_elem(n, k, Npad)).
 // Four consecutive channels of one pixel = one 8-byte store per plane.
-__device__ __forceinline__ void store_planes4(short* __restrict__ op, const long plane, const int np, const long e, const b3_f32x4 v) {
+__device__ __host__ __forceinline__ long plane_elem(const long pix, const int c, const long P) {
+    return (((long)(c >> 5) * P + pix) << 5) + (c & 31);
+}
+__device__ __forceinline__ void store_planes4(short* __restrict__ op, const long plane, const int np, const long pix, const int c,
+                                              const long P, const b3_f32x4 v) {
+    const long e = plane_elem(pix, c, P);
     if (np == 1) {
         *reinterpret_cast<uint2*>(op + e) = rne4(v);
     } else {
@@ -130,6 +139,12 @@ __device__ __forceinline__ void store_planes4(short* __restrict__ op, const long
         *reinterpret_cast<uint2*>(op + plane + e) = m;
         *reinterpret_cast<uint2*>(op + 2 * plane + e) = l;
     }
+}
+// ... from the element index e = pix * C + c of the fp32 tensor (the elementwise producers walk that)
+__device__ __forceinline__ void store_planes4_lin(short* __restrict__ op, const long plane, const int np, const long e, const int C,
+                                                  const long P, const b3_f32x4 v) {
+    const long pix = e / C;
+    store_planes4(op, plane, np, pix, (int)(e - pix * C), P, v);
 }
 
 }  // namespace ssd

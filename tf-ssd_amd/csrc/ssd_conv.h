@@ -189,8 +189,8 @@ long dma_grid_blocks(int i, const ConvParams& p);
 int dma_k_tiles(int np, const ConvParams& p);
 void dma_tile(int i, int* BM, int* BN);
 int dma_launch(const ConvParams& p, int i, int np, hipStream_t st);
-int launch_split_planes(const float* x, long n, int np, short* planes, long plane, hipStream_t st);
-int launch_join_planes(const short* planes, long n, int np, long plane, float* x, hipStream_t st);
+int launch_split_planes(const float* x, long n, int C, int np, short* planes, long plane, hipStream_t st);
+int launch_join_planes(const short* planes, long n, int C, int np, long plane, float* x, hipStream_t st);
 bool conv_config_is_dma(int cfg);          // either family
 bool conv_config_writes_planes(int cfg, const ConvParams& p);   // the family's epilogue (conv_epilogue / splitk_reduce_kernel) honours ConvParams::op
 
@@ -218,7 +218,9 @@ inline size_t conv_packed_floats(int K, int Cout) {
 inline const short* conv_split_planes(const float* packed, int K, int Cout) {
     return reinterpret_cast<const short*>(packed + (size_t)conv_kpad(K) * conv_npad(Cout));
 }
-int launch_pack_split(float* packed, int K, int Cout, hipStream_t st);     // after ALL launch_pack_weights calls of a buffer
+// after ALL launch_pack_weights calls of a buffer; planes slice-major [Kpad / 32][Npad][32] for the conv tiles (ssd_bf16x3.h),
+// row_major: plain [Npad][Kpad] (the whole-image block kernels' expand / project matrices)
+int launch_pack_split(float* packed, int K, int Cout, hipStream_t st, bool row_major = false);
 // out[r][c] = in[r][c] * scale[r] (rows >= nvalid copied unscaled); out[r][c] = in[r][c] * scale[c]
 int launch_scale_rows(const float* in, const float* scale, int rows, int nvalid, int cols, float* out, hipStream_t st);
 int launch_scale_cols(const float* in, const float* scale, int rows, int cols, float* out, hipStream_t st);

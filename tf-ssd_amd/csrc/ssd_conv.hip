@@ -69,7 +69,7 @@ __global__ void splitk_reduce_kernel(const ConvParams p) {
             t[j] = r;
         }
         // (dense outputs with Cout % 4 == 0 only: the four elements lie in one row)
-        if (V == 4 && p.op) store_planes4(p.op, p.op_plane, p.op_np, g * V, f32x4{t[0], t[1], t[2], t[3]});
+        if (V == 4 && p.op) store_planes4_lin(p.op, p.op_plane, p.op_np, g * V, p.Cout, p.M, f32x4{t[0], t[1], t[2], t[3]});
     }
 }
 
@@ -209,7 +209,7 @@ __global__ __launch_bounds__(256) void conv_stem_kernel(const ConvParams p) {
                 const long pix = m - (long)b * HoWo;
                 const f32x4 v = *reinterpret_cast<const f32x4*>(so + pl * 36 + c4 * 4);
                 *reinterpret_cast<f32x4*>(p.out + (long)b * p.out_batch_stride + pix * p.out_pixel_stride + cg + c4 * 4) = v;
-                if (p.op) store_planes4(p.op, p.op_plane, p.op_np, m * p.Cout + cg + c4 * 4, v);      // (dense outputs only)
+                if (p.op) store_planes4(p.op, p.op_plane, p.op_np, m, cg + c4 * 4, p.M, v);      // (dense outputs only)
             }
         }
     }
@@ -580,16 +580,16 @@ int ssd_conv2d_ex(const ssd_conv_desc* d, const float* in_dev, const float* pack
     return conv_launch(p, cfg, (hipStream_t)stream);
 }
 
-int ssd_split_planes(const float* x_dev, long n, int planes, void* planes_dev, long plane_stride, void* stream) {
+int ssd_split_planes(const float* x_dev, long n, int channels, int planes, void* planes_dev, long plane_stride, void* stream) {
     SSD_CHECK_ARG(x_dev && planes_dev && n >= 0, "ssd_split_planes: bad arguments");
     SSD_CHECK_ARG(plane_stride >= n && plane_stride % 8 == 0, "ssd_split_planes: plane_stride %ld must be >= n and a multiple of 8", plane_stride);
     SSD_CHECK_ARG((((uintptr_t)x_dev | (uintptr_t)planes_dev) & 15) == 0, "ssd_split_planes: pointers must be 16-byte aligned");
-    return launch_split_planes(x_dev, n, planes, static_cast<short*>(planes_dev), plane_stride, (hipStream_t)stream);
+    return launch_split_planes(x_dev, n, channels, planes, static_cast<short*>(planes_dev), plane_stride, (hipStream_t)stream);
 }
 
-int ssd_join_planes(const void* planes_dev, long n, int planes, long plane_stride, float* x_dev, void* stream) {
+int ssd_join_planes(const void* planes_dev, long n, int channels, int planes, long plane_stride, float* x_dev, void* stream) {
     SSD_CHECK_ARG(x_dev && planes_dev && n >= 0 && (planes == 1 || planes == 3) && plane_stride >= n, "ssd_join_planes: bad arguments");
-    return launch_join_planes(static_cast<const short*>(planes_dev), n, planes, plane_stride, x_dev, (hipStream_t)stream);
+    return launch_join_planes(static_cast<const short*>(planes_dev), n, channels, planes, plane_stride, x_dev, (hipStream_t)stream);
 }
 
 int ssd_conv2d_planes(const ssd_conv_desc* d, const void* in_planes_dev, int planes, long in_plane_stride,
@@ -615,8 +615,8 @@ int ssd_conv2d_planes(const ssd_conv_desc* d, const void* in_planes_dev, int pla
     p.out_batch_stride = out_batch_stride > 0 ? out_batch_stride : (long)p.Ho * p.Wo * p.out_pixel_stride;
     p.vec_store = (((uintptr_t)out_dev & 15) == 0) && (p.out_pixel_stride % 4 == 0) && (p.out_batch_stride % 4 == 0);
     if (out_planes_dev) {
-        SSD_CHECK_ARG(p.out_pixel_stride == p.Cout && p.out_batch_stride == (long)p.Ho * p.Wo * p.Cout && p.Cout % 4 == 0,
-                      "conv2d_planes: plane output needs a dense [B,Ho,Wo,Cout] destination with Cout %% 4 == 0");
+        SSD_CHECK_ARG(p.out_pixel_stride == p.Cout && p.out_batch_stride == (long)p.Ho * p.Wo * p.Cout && p.Cout % 32 == 0,
+                      "conv2d_planes: plane output needs a dense [B,Ho,Wo,Cout] destination with Cout %% 32 == 0 (whole channel slices)");
         SSD_CHECK_ARG(out_plane_stride >= p.M * p.Cout && out_plane_stride % 8 == 0, "conv2d_planes: bad out_plane_stride");
         p.op = static_cast<short*>(out_planes_dev); p.op_plane = out_plane_stride; p.op_np = planes;
     }

@@ -60,14 +60,19 @@ int c3_lds_bytes(const Conv3Cfg& g, int planes) {
 
 // four bf16 planes behind the packed fp32 weights: h, m, l (the exact split, x = h + m + l) and r = the bf16 rounding of
 // x (round to nearest even) for the one-product bf16 kernels
-__global__ __launch_bounds__(256) void pack_split_kernel(const float* __restrict__ w, const long total, short* __restrict__ out) {
+// (plane layout [Kpad / 32][Npad][32], ssd_bf16x3.h: a tile's 16 rows x 32 k are 1 KB of contiguous memory)
+// (row_major: plain [Npad][Kpad] planes -- what the whole-image block kernels stage themselves, ssd_imgblock.hip)
+__global__ __launch_bounds__(256) void pack_split_kernel(const float* __restrict__ w, const long total, const int Kpad, const int Npad,
+                                                         const int row_major, short* __restrict__ out) {
     for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+        const long n = e / Kpad;
+        const long d = row_major ? e : plane_elem(n, (int)(e - n * Kpad), Npad);
         short h, m, l;
         split1(w[e], h, m, l);
-        out[e] = h;
-        out[total + e] = m;
-        out[2 * total + e] = l;
-        out[3 * total + e] = rne1(w[e]);
+        out[d] = h;
+        out[total + d] = m;
+        out[2 * total + d] = l;
+        out[3 * total + d] = rne1(w[e]);
     }
 }
 
@@ -118,11 +123,12 @@ int mfma3_launch(const ConvParams& p, int i, hipStream_t st, bool bf16) {
     return SSD_OK;
 }
 
-int launch_pack_split(float* packed, int K, int Cout, hipStream_t st) {
+int launch_pack_split(float* packed, int K, int Cout, hipStream_t st, bool row_major) {
     const long total = (long)conv_kpad(K) * conv_npad(Cout);
     if (total == 0) return SSD_OK;
     const int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
-    hipLaunchKernelGGL(pack_split_kernel, dim3(blocks), dim3(256), 0, st, packed, total, const_cast<short*>(conv_split_planes(packed, K, Cout)));
+    hipLaunchKernelGGL(pack_split_kernel, dim3(blocks), dim3(256), 0, st, packed, total, conv_kpad(K), conv_npad(Cout), row_major ? 1 : 0,
+                       const_cast<short*>(conv_split_planes(packed, K, Cout)));
     SSD_LAUNCH_CHECK();
     return SSD_OK;
 }

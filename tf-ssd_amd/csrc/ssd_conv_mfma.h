@@ -104,7 +104,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, f32x4 (&acc)[
                 } else {
                     dst[0] = v[0]; dst[1] = v[1]; dst[2] = v[2]; dst[3] = v[3];
                 }
-                if (p.op) store_planes4(p.op, p.op_plane, p.op_np, (long)m * p.Cout + n, v);
+                if (p.op) store_planes4(p.op, p.op_plane, p.op_np, m, n, p.M, v);
             } else {
                 for (int j = 0; j < 4; ++j) {
                     if (n + j >= p.Cout) break;
@@ -180,14 +180,14 @@ __device__ __forceinline__ void conv_mfma_body(const ConvParams& p, float* __res
     int w3off[WP3], w3dst[WP3];
     const short* w3base = nullptr;
     if constexpr (SPLIT3) {
-        w3base = p.w3 + (long)n0 * p.Kpad;
+        w3base = p.w3 + (long)n0 * 32;              // planes [Kpad / 32][Npad][32]: row n of k-slice s at (s * Npad + n) * 32
 #pragma unroll
         for (int ps = 0; ps < WP3; ++ps) {
             const int u = min(tid + ps * NTHR, WU3 - 1);
             const int pl = u / (BN * 4), rem = u - pl * (BN * 4);
             const int row = rem >> 2, q = rem & 3;
             const int r = min(row, min(BN, p.Npad - n0) - 1);     // clamped: rows past the tile / Npad are never used
-            w3off[ps] = (pl + WPL) * p.Npad * p.Kpad + r * p.Kpad + q * 8;
+            w3off[ps] = (pl + WPL) * p.Npad * p.Kpad + r * 32 + q * 8;
             w3dst[ps] = (pl * BN + row) * 64 + ((q ^ ((row >> 1) & 3)) << 4);
         }
     }
@@ -384,7 +384,7 @@ __device__ __forceinline__ void conv_mfma_body(const ConvParams& p, float* __res
                 }
             }
 #pragma unroll
-            for (int ps = 0; ps < WP3; ++ps) W[ps] = *reinterpret_cast<const bf16x8*>(w3base + w3off[ps] + l_k0);
+            for (int ps = 0; ps < WP3; ++ps) W[ps] = *reinterpret_cast<const bf16x8*>(w3base + w3off[ps] + (long)l_k0 * p.Npad);
         };
         // three bf16 planes per operand, rows of 32 bf16 = 64 bytes: a thread's 4 k-values become 8 bytes per plane at
         // 16-byte quad (kq >> 1) ^ ((row >> 1) & 3), half kq & 1 (the fragment reads' swizzle); weights arrive split
@@ -546,7 +546,7 @@ __device__ __forceinline__ void conv_mfma_body(const ConvParams& p, float* __res
             };
             auto loadW = [&](bf16x8 (&W)[WP3], int k0) {
 #pragma unroll
-                for (int ps = 0; ps < WP3; ++ps) W[ps] = *reinterpret_cast<const bf16x8*>(w3base + w3off[ps] + k0);
+                for (int ps = 0; ps < WP3; ++ps) W[ps] = *reinterpret_cast<const bf16x8*>(w3base + w3off[ps] + (long)k0 * p.Npad);
             };
             // state here: tile kt_begin stored in stage 0; (xs0, ws0) hold tile kt_begin + 1 (if any), l_* describe it
             int k0_next = l_k0;                          // k offset of the tile whose WEIGHTS are loaded next (tile kt + 2)

@@ -3,7 +3,7 @@
 // conv_mfma3_kernel (ssd_conv3.hip) loads fp32 pixels into VGPRs, splits them into three bf16 planes with ~100 VALU
 // instructions per thread and K tile and writes 72 KB per K tile through ds_write (~80 B/clk/CU): its time is its matrix
 // time PLUS that staging (profiles/HISTORY.md, round 4: MFMA-only skeleton 0.78 of the split-bf16 peak, the kernel 0.44 -
-// 0.58).  Here the activation arrives PRE-SPLIT -- bf16 planes [np][B*H*W][Cin] written by its producer's epilogue
+// 0.58).  Here the activation arrives PRE-SPLIT -- bf16 planes [np][Cin / 32][B*H*W][32] (slice-major: ssd_bf16x3.h) written by its producer's epilogue
 // (store_planes4) or by split_planes_kernel -- next to the weights' planes (pack_split_kernel), and both operands are
 // copied global -> LDS by `buffer_load_dwordx4 ... lds` (LDS-DMA: 1 KB = 16 tile rows x 64 bytes per wave instruction, no
 // VGPR, no ds_write, no split):
@@ -50,8 +50,12 @@ __device__ __forceinline__ void conv_dma_body(const ConvParams& p, char* __restr
     const int r16 = lane >> 2;
     const int q8 = ((lane & 3) ^ ((lane >> 3) & 3)) * 8;
     const int b_first = (int)(m0 / HoWo);
-    const long xbase_e = GEMM1X1 ? m0 * p.Cin : (long)b_first * p.H * p.W * p.Cin;        // elements into a plane
-    const long xrange = min((long)0x7fffffffL, ((long)p.B * p.H * p.W * p.Cin - xbase_e) * 2);
+    // slice-major planes: pixel g, channel c at ((c / 32) * P + g) * 32 + c % 32, P = B H W.  The resource starts at the tile's
+    // first pixel (1x1) / first image of slice 0; a K tile's slice goes into the scalar offset (P * 64 bytes per slice)
+    const long npix = (long)p.B * p.H * p.W;
+    const long xbase_e = (GEMM1X1 ? m0 : (long)b_first * p.H * p.W) * 32;        // elements into a plane
+    const long xrange = min((long)0x7fffffffL, (npix * p.Cin - xbase_e) * 2);
+    const int slice_b = (int)(npix * 64);                                          // bytes between two 32-channel slices
     __amdgpu_buffer_rsrc_t xrs[NP];
 #pragma unroll
     for (int pl = 0; pl < NP; ++pl)
@@ -69,14 +73,14 @@ __device__ __forceinline__ void conv_dma_body(const ConvParams& p, char* __restr
         xvalid[j] = 0;
         if (rb < RBX && m < p.M) {
             if (GEMM1X1) {
-                xoff[j] = ((rb * 16 + r16) * p.Cin + q8) * 2;
+                xoff[j] = ((rb * 16 + r16) * 32 + q8) * 2;
                 xvalid[j] = 1u;
             } else {
                 const int b = (int)(m / HoWo);
                 const int pix = (int)(m - (long)b * HoWo);
                 const int oy = pix / p.Wo, ox = pix - oy * p.Wo;
                 const int iy0 = oy * p.stride - p.pad_t, ix0 = ox * p.stride - p.pad_l;
-                xoff[j] = ((((b - b_first) * p.H + iy0) * p.W + ix0) * p.Cin + q8) * 2;
+                xoff[j] = ((((b - b_first) * p.H + iy0) * p.W + ix0) * 32 + q8) * 2;
                 for (int ky = 0; ky < p.kh; ++ky)
                     for (int kx = 0; kx < p.kw; ++kx) {
                         const int iy = iy0 + ky * p.dil, ix = ix0 + kx * p.dil;
@@ -90,7 +94,7 @@ __device__ __forceinline__ void conv_dma_body(const ConvParams& p, char* __restr
     for (int j = 0; j < RPW; ++j) {
         const int rb = wave + j * NW;
         const int r = min(rb * 16 + r16, min(BN, p.Npad - n0) - 1);          // clamped: rows past the tile / Npad are never used
-        woff[j] = ((n0 + r) * p.Kpad + q8) * 2;
+        woff[j] = ((n0 + r) * 32 + q8) * 2;                                  // weights: [Kpad / 32][Npad][32] per plane
     }
 
     // ---- K walk: tiles of KS k-steps; general path channel-slice-major with the taps innermost (ssd_conv_mfma.h)
@@ -102,11 +106,12 @@ __device__ __forceinline__ void conv_dma_body(const ConvParams& p, char* __restr
         kt_begin = blockIdx.y * per;
         kt_end = min(ntiles, kt_begin + per);
     }
-    int l_k0 = 0, l_tap = 0, l_ci = 0, l_ky = 0, l_kx = 0, l_xtile = 0;
+    int l_k0 = 0, l_tap = 0, l_ci = 0, l_ky = 0, l_kx = 0, l_xtile = 0, l_xs = 0;
     auto tile_setup = [&](int kt) {
         if (GEMM1X1) {
             l_k0 = kt * 32 * KS;
-            l_xtile = l_k0 * 2;
+            l_xtile = 0;
+            l_xs = kt * KS * slice_b;
         } else {
             const int cs = kt / ntaps;
             l_tap = kt - cs * ntaps;
@@ -114,19 +119,21 @@ __device__ __forceinline__ void conv_dma_body(const ConvParams& p, char* __restr
             l_ky = l_tap / p.kw;
             l_kx = l_tap - l_ky * p.kw;
             l_k0 = l_tap * p.Cin + l_ci;
-            l_xtile = ((l_ky * p.dil * p.W + l_kx * p.dil) * p.Cin + l_ci) * 2;
+            l_xtile = (l_ky * p.dil * p.W + l_kx * p.dil) * 64;
+            l_xs = (l_ci >> 5) * slice_b;
         }
     };
     auto tile_advance = [&]() {
         if (GEMM1X1) {
             l_k0 += 32 * KS;
-            l_xtile += 64 * KS;
+            l_xs += KS * slice_b;
         } else {
             ++l_tap;
             if (++l_kx == p.kw) { l_kx = 0; ++l_ky; }
             if (l_tap == ntaps) { l_tap = 0; l_ky = 0; l_kx = 0; l_ci += 32 * KS; }
             l_k0 = l_tap * p.Cin + l_ci;
-            l_xtile = ((l_ky * p.dil * p.W + l_kx * p.dil) * p.Cin + l_ci) * 2;
+            l_xtile = (l_ky * p.dil * p.W + l_kx * p.dil) * 64;
+            l_xs = (l_ci >> 5) * slice_b;
         }
     };
     // k-steps of the tile at l_k0 that exist (1x1 path with KS = 2: the last tile may hold one)
@@ -146,7 +153,7 @@ __device__ __forceinline__ void conv_dma_body(const ConvParams& p, char* __restr
                 if (KS > 1 && s >= ns) break;
 #pragma unroll
                 for (int pl = 0; pl < NP; ++pl)
-                    __builtin_amdgcn_raw_ptr_buffer_load_lds(xrs[pl], (lds_dst_t)(sb + ((s * NP + pl) * BM + rb * 16) * 64), 16, vo, s * 64, 0, 0);
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(xrs[pl], (lds_dst_t)(sb + ((s * NP + pl) * BM + rb * 16) * 64), 16, vo, l_xs + s * slice_b, 0, 0);
             }
         }
 #pragma unroll
@@ -159,7 +166,7 @@ __device__ __forceinline__ void conv_dma_body(const ConvParams& p, char* __restr
 #pragma unroll
                 for (int pl = 0; pl < NP; ++pl)
                     __builtin_amdgcn_raw_ptr_buffer_load_lds(wrs, (lds_dst_t)(sb + XBYTES + ((s * NP + pl) * BN + rb * 16) * 64), 16, woff[j],
-                                                             (int)((pl + WPL) * wplane_b) + (l_k0 + s * 32) * 2, 0, 0);
+                                                             (int)((pl + WPL) * wplane_b) + ((l_k0 >> 5) + s) * p.Npad * 64, 0, 0);
             }
         }
     };
@@ -262,20 +269,24 @@ bool cd_gemm1x1(const ConvParams& p) {
 
 // fp32 activation -> bf16 planes (np = 3: exact split; np = 1: bf16 rounding); the fallback producer of a tensor whose
 // own producing kernel has no plane epilogue
-__global__ __launch_bounds__(256) void split_planes_kernel(const float* __restrict__ x, const long n4, const int np,
+__global__ __launch_bounds__(256) void split_planes_kernel(const float* __restrict__ x, const long n4, const int C, const int np,
                                                            short* __restrict__ planes, const long plane) {
+    const long P = n4 * 4 / C;
     for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < n4; e += (long)gridDim.x * 256)
-        store_planes4(planes, plane, np, e * 4, *reinterpret_cast<const f32x4*>(x + e * 4));
+        store_planes4_lin(planes, plane, np, e * 4, C, P, *reinterpret_cast<const f32x4*>(x + e * 4));
 }
 
 // bf16 planes -> fp32 (h + m + l is exact; np = 1: the rounded value): debug fetches / tests
-__global__ __launch_bounds__(256) void join_planes_kernel(const short* __restrict__ planes, const long n, const int np,
+__global__ __launch_bounds__(256) void join_planes_kernel(const short* __restrict__ planes, const long n, const int C, const int np,
                                                           const long plane, float* __restrict__ x) {
+    const long P = n / C;
     for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < n; e += (long)gridDim.x * 256) {
-        float v = __uint_as_float((unsigned)(unsigned short)planes[e] << 16);
+        const long pix = e / C;
+        const long s = plane_elem(pix, (int)(e - pix * C), P);
+        float v = __uint_as_float((unsigned)(unsigned short)planes[s] << 16);
         if (np == 3) {
-            v += __uint_as_float((unsigned)(unsigned short)planes[plane + e] << 16);
-            v += __uint_as_float((unsigned)(unsigned short)planes[2 * plane + e] << 16);
+            v += __uint_as_float((unsigned)(unsigned short)planes[plane + s] << 16);
+            v += __uint_as_float((unsigned)(unsigned short)planes[2 * plane + s] << 16);
         }
         x[e] = v;
     }
@@ -291,10 +302,12 @@ bool dma_config_valid(int i, int np, const ConvParams& p) {
     if (((uintptr_t)p.xp & 15) || ((uintptr_t)p.w3 & 15) || (p.xp_plane & 7)) return false;
     if (p.M > 0x7fffffffL - 1024) return false;
     if (4 * (long)p.Npad * p.Kpad * 2 > 0x7fffffffL) return false;
+    // slice-major planes: a K tile's channel slice is a scalar offset of up to the whole plane (31 bits)
+    if ((long)p.B * p.H * p.W * p.Cin * 2 > 0x7fffffffL) return false;
     if (cd_gemm1x1(p)) return p.Cin % 32 == 0;
     if (p.kh * p.kw > 32) return false;
-    // a tile's rows span at most BM / (Ho Wo) + 2 images: their offsets must fit 31 bits
-    if (((long)kCfgD[i].BM / (p.Ho * p.Wo) + 3) * p.H * p.W * p.Cin * 2 > 0x3fffffffL) return false;
+    // a tile's rows span at most BM / (Ho Wo) + 2 images: their per-lane offsets (64 bytes per pixel) must fit 31 bits
+    if (((long)kCfgD[i].BM / (p.Ho * p.Wo) + 3) * p.H * p.W * 64 > 0x3fffffffL) return false;
     return p.Cin % (np == 1 ? 64 : 32) == 0;
 }
 long dma_grid_blocks(int i, const ConvParams& p) {
@@ -324,20 +337,22 @@ int dma_launch(const ConvParams& p, int i, int np, hipStream_t st) {
     return SSD_OK;
 }
 
-int launch_split_planes(const float* x, long n, int np, short* planes, long plane, hipStream_t st) {
+int launch_split_planes(const float* x, long n, int C, int np, short* planes, long plane, hipStream_t st) {
     SSD_CHECK_ARG(n % 4 == 0 && (np == 1 || np == 3), "split_planes: element count %ld must be a multiple of 4, planes 1 or 3", n);
+    SSD_CHECK_ARG(C > 0 && C % 32 == 0 && n % C == 0, "split_planes: %d channels (slice-major planes need a multiple of 32 that divides the %ld elements)", C, n);
     if (n == 0) return SSD_OK;
     const long n4 = n / 4;
     const int blocks = (int)((n4 + 255) / 256 < 16384 ? (n4 + 255) / 256 : 16384);
-    hipLaunchKernelGGL(split_planes_kernel, dim3(blocks), dim3(256), 0, st, x, n4, np, planes, plane);
+    hipLaunchKernelGGL(split_planes_kernel, dim3(blocks), dim3(256), 0, st, x, n4, C, np, planes, plane);
     SSD_LAUNCH_CHECK();
     return SSD_OK;
 }
 
-int launch_join_planes(const short* planes, long n, int np, long plane, float* x, hipStream_t st) {
+int launch_join_planes(const short* planes, long n, int C, int np, long plane, float* x, hipStream_t st) {
     if (n == 0) return SSD_OK;
+    SSD_CHECK_ARG(C > 0 && C % 32 == 0 && n % C == 0, "join_planes: %d channels do not divide the %ld elements into whole 32-channel slices", C, n);
     const int blocks = (int)((n + 255) / 256 < 16384 ? (n + 255) / 256 : 16384);
-    hipLaunchKernelGGL(join_planes_kernel, dim3(blocks), dim3(256), 0, st, planes, n, np, plane, x);
+    hipLaunchKernelGGL(join_planes_kernel, dim3(blocks), dim3(256), 0, st, planes, n, C, np, plane, x);
     SSD_LAUNCH_CHECK();
     return SSD_OK;
 }

@@ -231,7 +231,7 @@ __global__ __launch_bounds__(kIThreads) void mbv2_image_block_kernel(const Fused
             if (p.e_out && real[t]) {
                 const long eo = ((long)img * H * W + opix[t]) * p.Ce + cbeg + j * kIC + g4 * 4;
                 *reinterpret_cast<f32x4*>(p.e_out + eo) = v;
-                if (p.e_planes) store_planes4(p.e_planes, p.e_plane, p.planes_np, eo, v);
+                if (p.e_planes) store_planes4(p.e_planes, p.e_plane, p.planes_np, (long)img * H * W + opix[t], cbeg + j * kIC + g4 * 4, (long)B * H * W, v);
             }
         }
     };
@@ -323,7 +323,7 @@ __global__ __launch_bounds__(kIThreads) void mbv2_image_block_kernel(const Fused
                 if (p.residual)                                     // Cin == Cout: same layout as y
                     v = v + *reinterpret_cast<const f32x4*>(p.x + img_off + (long)opo[t] * p.Cout + ni * 16 + g4 * 4);
                 *reinterpret_cast<f32x4*>(yp + ni * 16) = v;
-                if (p.y_planes) store_planes4(p.y_planes, p.y_plane, p.planes_np, img_off + (long)opo[t] * p.Cout + g4 * 4 + ni * 16, v);
+                if (p.y_planes) store_planes4(p.y_planes, p.y_plane, p.planes_np, (long)img * Ho * Wo + opo[t], g4 * 4 + ni * 16, (long)B * Ho * Wo, v);
             }
         }
         ITICK(5);
@@ -592,7 +592,7 @@ __global__ __launch_bounds__(kIThreads) void mbv2_image16_block_kernel(const Fus
             if (p.e_out && real[t]) {
                 const long eo = ((long)img * H * W + opix[t]) * p.Ce + cbeg + j * kIC + g4 * 4;
                 *reinterpret_cast<f32x4*>(p.e_out + eo) = v;
-                if (p.e_planes) store_planes4(p.e_planes, p.e_plane, p.planes_np, eo, v);
+                if (p.e_planes) store_planes4(p.e_planes, p.e_plane, p.planes_np, (long)img * H * W + opix[t], cbeg + j * kIC + g4 * 4, (long)B * H * W, v);
             }
         }
     };
@@ -693,7 +693,7 @@ __global__ __launch_bounds__(kIThreads) void mbv2_image16_block_kernel(const Fus
                 if (p.residual)
                     v = v + *reinterpret_cast<const f32x4*>(p.x + img_off + (long)opo[t] * p.Cout + ni * 16 + g4 * 4);
                 *reinterpret_cast<f32x4*>(yp + ni * 16) = v;
-                if (p.y_planes) store_planes4(p.y_planes, p.y_plane, p.planes_np, img_off + (long)opo[t] * p.Cout + g4 * 4 + ni * 16, v);
+                if (p.y_planes) store_planes4(p.y_planes, p.y_plane, p.planes_np, (long)img * Ho * Wo + opo[t], g4 * 4 + ni * 16, (long)B * Ho * Wo, v);
             }
         }
         I16TICK(5);
@@ -734,7 +734,7 @@ __global__ __launch_bounds__(256) void image_combine_kernel(const float* __restr
         }
         if (xres) v = v + *reinterpret_cast<const f32x4*>(xres + e * 4);
         *reinterpret_cast<f32x4*>(y + e * 4) = v;
-        if (yp) store_planes4(yp, y_plane, np, e * 4, v);
+        if (yp) store_planes4(yp, y_plane, np, e / c4n, (int)(e % c4n) * 4, nvec / c4n, v);
     }
 }
 

@@ -439,7 +439,7 @@ static int run_layer(ssd_net& net, const Layer& l, int B, float* deltas_out, flo
 // fp32 activation -> its bf16 planes (producers without a plane epilogue)
 static int planes_pass(ssd_net& net, int tensor, int B, hipStream_t st) {
     Tensor& t = net.tensors[tensor];
-    return launch_split_planes(t.dev, (long)B * (long)t.per_image, t.planes_np, t.planes, t.plane_stride, st);
+    return launch_split_planes(t.dev, (long)B * (long)t.per_image, t.C, t.planes_np, t.planes, t.plane_stride, st);
 }
 
 static int run_layer_kernels(ssd_net& net, const Layer& l, int B, float* deltas_out, float* probs_out, hipStream_t st,
@@ -974,8 +974,8 @@ int ssd_net_finalize(ssd_net* net, int max_batch) {
         if (!rc) rc = launch_scale_cols(net->params[ld.p_kernel].dev, ld.scale, 9, ld.Cout, f.fz_wd, st);
         if (!rc) rc = launch_scale_rows(lp.packed, lp.scale, conv_npad(lp.Cout), lp.Cout, conv_kpad(lp.Cin), f.fz_wp, st);
         // bf16 planes (h, m, l exact split + r rounding) of both: the bf16 form of the whole-image kernel reads plane r
-        if (!rc) rc = launch_pack_split(f.fz_we, le.Cin, le.Cout, st);
-        if (!rc) rc = launch_pack_split(f.fz_wp, lp.Cin, lp.Cout, st);
+        if (!rc) rc = launch_pack_split(f.fz_we, le.Cin, le.Cout, st, true);
+        if (!rc) rc = launch_pack_split(f.fz_wp, lp.Cin, lp.Cout, st, true);
         if (rc) return rc;
         // split-bf16 band kernel: the same two matrices as three bf16 planes each (exact split, see ssd_band3.hip)
         f.fz_we3 = f.fz_wp3 = nullptr;
@@ -1670,7 +1670,7 @@ long ssd_net_fetch_planes(ssd_net* net, const char* layer, float* host_out, size
     ScopedDev tmp;
     SSD_HIP(hipMalloc((void**)&tmp.p, n * sizeof(float)));
     SSD_HIP(hipDeviceSynchronize());
-    const int rc = launch_join_planes(t.planes, (long)n, t.planes_np, t.plane_stride, tmp.p, nullptr);
+    const int rc = launch_join_planes(t.planes, (long)n, t.C, t.planes_np, t.plane_stride, tmp.p, nullptr);
     if (rc) return rc;
     if (hipDeviceSynchronize() != hipSuccess || hipMemcpy(host_out, tmp.p, n * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess) {
         set_error("ssd_net_fetch_planes: copy failed");

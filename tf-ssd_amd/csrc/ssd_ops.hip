@@ -126,7 +126,7 @@ __global__ __launch_bounds__(256) void maxpool_kernel(const float* __restrict__ 
             }
         }
         *reinterpret_cast<f32x4*>(out + e * 4) = m;
-        if (planes) store_planes4(planes, plane, np, e * 4, m);      // the bf16 planes the LDS-DMA conv tiles read (ssd_convdma.hip)
+        if (planes) store_planes4(planes, plane, np, e / C4, c, (long)B * Ho * Wo, m);      // the bf16 planes the LDS-DMA conv tiles read (ssd_convdma.hip)
     }
 }
 
@@ -165,7 +165,7 @@ __global__ __launch_bounds__(256) void l2norm_kernel(const float* __restrict__ i
             const f32x4 g = *reinterpret_cast<const f32x4*>(gamma + c);
             const f32x4 y = v * inv * g;
             *reinterpret_cast<f32x4*>(out + px * C + c) = y;
-            if (planes) store_planes4(planes, plane, np, px * C + c, y);
+            if (planes) store_planes4(planes, plane, np, px, c, pixels, y);
         }
     }
 }

@@ -163,14 +163,15 @@ __global__ __launch_bounds__(256) void pack_jobs_kernel(const PackJob* __restric
         // ssd_conv3.hip) and the bf16 rounding r (bf16 tiles)
         // (only the planes this precision's tiles read: the re-pack runs every step)
         short* pl = reinterpret_cast<short*>(j.dst + total);
+        const long d = plane_elem(n, k, j.Npad);          // planes: [Kpad / 32][Npad][32] (ssd_bf16x3.h)
         if (j.bf16) {
-            pl[3 * (long)total + e] = rne1(v);
+            pl[3 * (long)total + d] = rne1(v);
         } else {
             short h, m, l;
             split1(v, h, m, l);
-            pl[e] = h;
-            pl[(long)total + e] = m;
-            pl[2 * (long)total + e] = l;
+            pl[d] = h;
+            pl[(long)total + d] = m;
+            pl[2 * (long)total + d] = l;
         }
     }
 }

@@ -85,8 +85,8 @@ _SIGNATURES = {
     "ssd_conv_config_name": (ctypes.c_char_p, [ctypes.c_int]),
     "ssd_conv2d_ex": (ctypes.c_int, [ctypes.POINTER(ConvDesc), vp, vp, vp, vp, vp, vp,
                                      ctypes.c_long, ctypes.c_long, ctypes.c_int, ctypes.c_int, vp, vp]),
-    "ssd_split_planes": (ctypes.c_int, [vp, ctypes.c_long, ctypes.c_int, vp, ctypes.c_long, vp]),
-    "ssd_join_planes": (ctypes.c_int, [vp, ctypes.c_long, ctypes.c_int, ctypes.c_long, vp, vp]),
+    "ssd_split_planes": (ctypes.c_int, [vp, ctypes.c_long, ctypes.c_int, ctypes.c_int, vp, ctypes.c_long, vp]),
+    "ssd_join_planes": (ctypes.c_int, [vp, ctypes.c_long, ctypes.c_int, ctypes.c_int, ctypes.c_long, vp, vp]),
     "ssd_conv2d_planes": (ctypes.c_int, [ctypes.POINTER(ConvDesc), vp, ctypes.c_int, ctypes.c_long, vp, vp, vp, vp, vp,
                                          ctypes.c_long, ctypes.c_long, vp, ctypes.c_long, ctypes.c_int, ctypes.c_int, vp, vp]),
     "ssd_conv_wino_weight_floats": (ctypes.c_size_t, [ctypes.c_int, ctypes.c_int]),
