@@ -30,16 +30,17 @@ base_table = base_model.get_tuning()
 
 VARIANTS = [
     ("shipped", {}),
-    ("head1 2x7_8x1/s2", {"1_conv_heads": "mfma3_2x7_8x1 2"}),
-    ("head1 2x7_8x1/s1", {"1_conv_heads": "mfma3_2x7_8x1 1"}),
-    ("head1 2x4_6x2/s1", {"1_conv_heads": "mfma3_2x4_6x2 1"}),
-    ("head1 4x4_4x2/s2", {"1_conv_heads": "mfma3_4x4_4x2 2"}),
-    ("head2 4x5_4x2/s5", {"2_conv_heads": "mfma3_4x5_4x2 5"}),
-    ("head2 4x5_4x2/s2", {"2_conv_heads": "mfma3_4x5_4x2 2"}),
-    ("head2 2x5_2x2/s4", {"2_conv_heads": "mfma3_2x5_2x2 4"}),
-    ("head1 2x7_8x1/s2 + head2 4x5_4x2/s5", {"1_conv_heads": "mfma3_2x7_8x1 2", "2_conv_heads": "mfma3_4x5_4x2 5"}),
+    ("head1 dma3_2x4_6x2/s2", {"1_conv_heads": "dma3_2x4_6x2 2"}),
+    ("head2 dma3_4x5_4x2/s8", {"2_conv_heads": "dma3_4x5_4x2 8"}),
+    ("head2 dma3_4x5_4x2/s10", {"2_conv_heads": "dma3_4x5_4x2 10"}),
+    ("heads 1 + 2 on dma3", {"1_conv_heads": "dma3_2x4_6x2 2", "2_conv_heads": "dma3_4x5_4x2 8"}),
+    ("heads 1 + 2 + extra1_1 / 1_2 on dma3", {"1_conv_heads": "dma3_2x4_6x2 2", "2_conv_heads": "dma3_4x5_4x2 8",
+                                              "extra1_1": "dma3_2x4_4x2 2", "extra1_2": "dma3_2x4_4x2 4"}),
     ("shipped again", {}),
 ]
+if os.environ.get("VARIANTS"):          # "name=layer:config split,layer:config split;name=..." replaces the list above
+    VARIANTS = [("shipped", {})] + [(v.split("=", 1)[0], dict(kv.split(":", 1) for kv in v.split("=", 1)[1].split(",")))
+                                    for v in os.environ["VARIANTS"].split(";")]
 
 
 def table_with(repl):
