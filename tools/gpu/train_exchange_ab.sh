@@ -1,4 +1,5 @@
 #!/bin/bash
+# the training step plain / through the forced single-rank exchange with 1 - 8 gradient buckets, weight gradients on or beside the main stream
 OUT=gpurun_out/r5i; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 run() { tag=$1; shift
