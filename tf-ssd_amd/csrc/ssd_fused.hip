@@ -495,13 +495,24 @@ constexpr int kSTH = 8, kSTW = 16;
 constexpr int kSIH = kSTH + 2, kSIW = kSTW + 2;           // Conv1 halo tile 10 x 18
 constexpr int kSPH = 2 * (kSIH - 1) + 3, kSPW = 2 * (kSIW - 1) + 3;   // image patch 21 x 37
 constexpr int kSLD = 40;                                  // LDS row stride of the 32-channel tiles (10 quads: conflict-free b128 fragment reads)
+// DMA form of the patch (round 5): rows start at a 16-byte aligned float (up to 3 floats left of the patch's first), 29 quads =
+// 116 floats per row, TWO stages: tile t + 1's rows are copied global -> LDS by `buffer_load_dwordx4 ... lds` while tile t is
+// computed (the register-staged patch load cost 20 of the kernel's 112 us: tests/micro/stem_ablate.py, SSD_STEM_ABLATE = 8 / 16)
+constexpr int kSPQ = (kSPW * 3 + 3 + 3) / 4, kSPR = kSPQ * 4;
+constexpr int kSPS = (kSPH * kSPQ + 63) / 64 * 256;       // floats per patch stage: whole 64-lane instructions (640 units)
 
-template <int NP>
-__global__ __launch_bounds__(256) void mbv2_stem_kernel(const StemParams p) {
-    __shared__ __attribute__((aligned(16))) float sm[kSPH * kSPW * 3 + 5 + kSIH * kSIW * kSLD + kSTH * kSTW * kSLD +
-                                                       27 * 32 + 9 * 32 + 16 * kSLD + 32 * 2 + 32 * 2 + 16 * 2];
-    float* patch = sm;                                         // [21*37*3] image patch (+5 pad)
-    float* C1 = patch + kSPH * kSPW * 3 + 5;                   // [180][36] Conv1 output (halo), 16-byte aligned
+template <bool DMA>
+constexpr int stem_patch_floats() { return DMA ? 2 * kSPS : kSPH * kSPW * 3 + 5; }
+template <bool DMA>
+constexpr int stem_lds_floats() {
+    return stem_patch_floats<DMA>() + kSIH * kSIW * kSLD + kSTH * kSTW * kSLD + 27 * 32 + 9 * 32 + 16 * kSLD + 32 * 2 + 32 * 2 + 16 * 2;
+}
+// (a __device__ body: a __global__ function that declares buffer resources loses its host stub)
+template <int NP, bool DMA>
+__device__ __forceinline__ void stem_body(const StemParams& p, float* __restrict__ sm) {
+    constexpr int RP = DMA ? kSPR : kSPW * 3;                  // floats between two patch rows in LDS
+    float* patch = sm;                                         // [21*37*3] image patch (+5 pad); DMA: [2][640 units of 4]
+    float* C1 = patch + stem_patch_floats<DMA>();              // [180][36] Conv1 output (halo), 16-byte aligned
     float* D = C1 + kSIH * kSIW * kSLD;                        // [128][36] depthwise output
     float* W1 = D + kSTH * kSTW * kSLD;                        // [27][32] Conv1 weights * BN scale
     float* Wd = W1 + 27 * 32;                                  // [9][32]  depthwise weights * BN scale
@@ -518,6 +529,7 @@ __global__ __launch_bounds__(256) void mbv2_stem_kernel(const StemParams p) {
     // packed-FMA rate: 63 of the kernel's 131 us), and the patch offsets of ITS four k per k-block
     f32x4 w1a[2][2];
     int koff[2][4];
+    int kcol[2][4];            // kx * 3 + ci of the lane's k values (DMA form: the right-edge mask)
     // NP > 0: one 32-wide k-step; lane (ch = l15, g4) holds k = g4*8 .. +7 of both channel tiles as bf16 planes, and the
     // project's A fragment (row n = l15) the same way
     BP<NP ? NP : 1> w1b[2], wpb;
@@ -527,7 +539,8 @@ __global__ __launch_bounds__(256) void mbv2_stem_kernel(const StemParams p) {
 #pragma unroll
             for (int s4 = 0; s4 < 4; ++s4) {
                 const int k = kb * 16 + (lane >> 4) * 4 + s4;
-                koff[kb][s4] = k < 27 ? (k / 9) * (kSPW * 3) + (k % 9) : 0;      // (ky, kx*3 + ci) inside the patch
+                koff[kb][s4] = k < 27 ? (k / 9) * RP + (k % 9) : 0;      // (ky, kx*3 + ci) inside the patch
+                kcol[kb][s4] = k < 27 ? k % 9 : 0;
 #pragma unroll
                 for (int ct = 0; ct < 2; ++ct) {
                     const int ch = ct * 16 + (lane & 15);
@@ -539,7 +552,8 @@ __global__ __launch_bounds__(256) void mbv2_stem_kernel(const StemParams p) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const int k = (lane >> 4) * 8 + j;
-            koff[j >> 2][j & 3] = k < 27 ? (k / 9) * (kSPW * 3) + (k % 9) : 0;
+            koff[j >> 2][j & 3] = k < 27 ? (k / 9) * RP + (k % 9) : 0;
+            kcol[j >> 2][j & 3] = k < 27 ? k % 9 : 0;
 #pragma unroll
             for (int ct = 0; ct < 2; ++ct) {
                 const int ch = ct * 16 + (lane & 15);
@@ -563,16 +577,61 @@ __global__ __launch_bounds__(256) void mbv2_stem_kernel(const StemParams p) {
 
     const int tiles_per_img = p.tiles_y * p.tiles_x;
     const long total_tiles = (long)p.B * tiles_per_img;
-    for (long tile = blockIdx.x; tile < total_tiles; tile += gridDim.x) {
-        const int b = (int)(tile / tiles_per_img);
+    // DMA form: the patch rows as 16-byte units u = row * 29 + quad, 609 of them = 10 wave-instructions, wave w issues
+    // instructions w, w + 4, w + 8; a unit's LDS slot is u * 16 bytes (the rows are 29 quads apart).  Source rows start at
+    // float fs = floor(ix0 * 3 / 4) * 4 of image row iy0 + row; rows outside the image and offsets before the image's first byte
+    // are out of the resource's range: the hardware writes zeros (the padding).  Floats beyond the row's end hold the next row's
+    // first pixels: the right-edge tiles mask them in the gather.
+    int du_row[3], du_q[3];
+    if (DMA) {
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const int u = (wave + 4 * j) * 64 + lane;
+            du_row[j] = u / kSPQ;
+            du_q[j] = u - du_row[j] * kSPQ;
+        }
+    }
+    auto tile_origin = [&](long tile, int& b, int& oy0, int& ox0, int& iy0, int& ix0) {
+        b = (int)(tile / tiles_per_img);
         const int rem = (int)(tile - (long)b * tiles_per_img);
         const int ty = rem / p.tiles_x, tx = rem - ty * p.tiles_x;
-        const int oy0 = ty * kSTH, ox0 = tx * kSTW;               // output tile origin (150 x 150 grid)
-        const int cy0 = oy0 - 1, cx0 = ox0 - 1;                    // Conv1-output halo origin (dw SAME pad 1)
-        const int iy0 = cy0 * 2 - p.pad_t, ix0 = cx0 * 2 - p.pad_l;   // image patch origin
+        oy0 = ty * kSTH; ox0 = tx * kSTW;                          // output tile origin (150 x 150 grid)
+        iy0 = (oy0 - 1) * 2 - p.pad_t; ix0 = (ox0 - 1) * 2 - p.pad_l;   // image patch origin (Conv1-output halo origin: dw SAME pad 1)
+    };
+    auto issue_patch = [&](long tile, int stage) {
+        if constexpr (DMA) {
+            int b, oy0, ox0, iy0, ix0;
+            tile_origin(tile, b, oy0, ox0, iy0, ix0);
+            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x + (long)b * p.H * p.W * 3), 0,
+                                                                               p.H * p.W * 12, 0x00020000);
+            const int fs = ((ix0 * 3) >> 2) * 4;                   // (arithmetic shift: floor for negative origins)
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                const int ii = __builtin_amdgcn_readfirstlane(wave) + 4 * j;       // (wave-uniform: the LDS base goes to M0)
+                if (ii * 64 >= kSPH * kSPQ) continue;
+                const int iy = iy0 + du_row[j];
+                const bool ok = du_row[j] < kSPH && (unsigned)iy < (unsigned)p.H;
+                const int off = ok ? (iy * p.W * 3 + fs + du_q[j] * 4) * 4 : (int)0x80000000;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(patch + stage * kSPS + ii * 256), 16, off, 0, 0, 0);
+            }
+        }
+    };
+    if (DMA && blockIdx.x < total_tiles) issue_patch(blockIdx.x, 0);
+    int it = 0;
+    for (long tile = blockIdx.x; tile < total_tiles; tile += gridDim.x, ++it) {
+        int b, oy0, ox0, iy0, ix0;
+        tile_origin(tile, b, oy0, ox0, iy0, ix0);
+        const int cy0 = oy0 - 1, cx0 = ox0 - 1;
         const float* img = p.x + (long)b * p.H * p.W * 3;
+        const float* pbuf = patch;                                  // this tile's patch; psh: floats between a row's first float and ix0
+        int psh = 0;
 
-        __syncthreads();        // previous tile fully consumed (and the weights are visible)
+        __syncthreads();        // previous tile fully consumed (and the weights are visible); DMA: this tile's patch has landed (vmcnt)
+        if constexpr (DMA) {
+            pbuf = patch + (it & 1) * kSPS;
+            psh = ix0 * 3 - ((ix0 * 3) >> 2) * 4;
+            if (tile + gridDim.x < total_tiles) issue_patch(tile + gridDim.x, (it + 1) & 1);      // that stage was read by the PREVIOUS tile's Conv1
+        } else {
         // image patch: 21 rows x 111 contiguous floats
         {
             constexpr int NLD = (kSPH * kSPW * 3 + 255) / 256;
@@ -593,6 +652,11 @@ __global__ __launch_bounds__(256) void mbv2_stem_kernel(const StemParams p) {
             }
         }
         __syncthreads();
+        }
+        // DMA form, tiles whose patch crosses the image's right edge: floats at or beyond (W - ix0) * 3 of a row are not padding
+        // but the next row's pixels -> read as zero
+        const int xlim = (p.W - ix0) * 3;
+        const bool xedge = DMA && xlim < kSPW * 3;
 
         // ---- Conv1 on the halo (MFMA): 12 pixel tiles of 16 halo pixels, 3 per wave; B fragment = the
         //      lane's pixel x its 4 k of the k-block, gathered from the patch with 4 ds_read_b32
@@ -607,7 +671,7 @@ __global__ __launch_bounds__(256) void mbv2_stem_kernel(const StemParams p) {
                 const int hpc = hp[q] < NHP ? hp[q] : NHP - 1;      // the last tile's tail reads a valid pixel, never stored
                 rr[q] = hpc / kSIW;
                 cc[q] = hpc - rr[q] * kSIW;
-                pp[q] = patch + ((2 * rr[q]) * kSPW + 2 * cc[q]) * 3;
+                pp[q] = pbuf + (2 * rr[q]) * RP + 2 * cc[q] * 3 + psh;
                 a0[q] = *reinterpret_cast<const f32x4*>(H1 + (lane >> 4) * 4);
                 a1[q] = *reinterpret_cast<const f32x4*>(H1 + 16 + (lane >> 4) * 4);
             }
@@ -620,6 +684,10 @@ __global__ __launch_bounds__(256) void mbv2_stem_kernel(const StemParams p) {
                         float bq[3];
 #pragma unroll
                         for (int q = 0; q < 3; ++q) bq[q] = pp[q][koff[kb][s4]];
+                        if (xedge)
+#pragma unroll
+                            for (int q = 0; q < 3; ++q)
+                                if (cc[q] * 6 + kcol[kb][s4] >= xlim) bq[q] = 0.f;
 #pragma unroll
                         for (int q = 0; q < 3; ++q) {
                             a0[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(w1a[0][kb][s4], bq[q], a0[q], 0, 0, 0);
@@ -634,6 +702,13 @@ __global__ __launch_bounds__(256) void mbv2_stem_kernel(const StemParams p) {
                     for (int j = 0; j < 4; ++j) {
                         lo[j] = pp[q][koff[0][j]];
                         hi[j] = pp[q][koff[1][j]];
+                    }
+                    if (xedge) {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            if (cc[q] * 6 + kcol[0][j] >= xlim) lo[j] = 0.f;
+                            if (cc[q] * 6 + kcol[1][j] >= xlim) hi[j] = 0.f;
+                        }
                     }
                     const BP<NP ? NP : 1> b = splitN<NP ? NP : 1>(lo, hi);
                     a0[q] = mmaN<NP ? NP : 1>(w1b[0], b, a0[q]);
@@ -724,6 +799,12 @@ __global__ __launch_bounds__(256) void mbv2_stem_kernel(const StemParams p) {
     }
 }
 
+template <int NP, bool DMA>
+__global__ __launch_bounds__(256) void mbv2_stem_kernel(const StemParams p) {
+    __shared__ __attribute__((aligned(1024))) float sm[stem_lds_floats<DMA>()];
+    stem_body<NP, DMA>(p, sm);
+}
+
 bool stem_supported(const StemParams& p) { return p.H1 >= 1 && p.W1 >= 1; }
 
 // Which form of the stem kernel runs for a net of this precision: 1 = bf16 operands (precision 1), 3 = the split-bf16
@@ -742,7 +823,11 @@ int launch_stem(StemParams p, hipStream_t st) {
     static const int ablate = getenv("SSD_STEM_ABLATE") ? atoi(getenv("SSD_STEM_ABLATE")) : 0;
     p.ablate = ablate;
     const int form = stem_form(p.bf16);
-    const auto fn = form == 1 ? mbv2_stem_kernel<1> : form == 3 ? mbv2_stem_kernel<3> : mbv2_stem_kernel<0>;
+    // the DMA form's source rows must start 16-byte aligned: W % 4 == 0 and a 16-byte aligned batch (SSD_STEM_DMA=0: diagnostics)
+    static const bool want_dma = !(getenv("SSD_STEM_DMA") && atoi(getenv("SSD_STEM_DMA")) == 0);
+    const bool dma = want_dma && p.W % 4 == 0 && (((uintptr_t)p.x) & 15) == 0 && (long)p.H * p.W * 12 < 0x7fffffffL;
+    const auto fn = dma ? (form == 1 ? mbv2_stem_kernel<1, true> : form == 3 ? mbv2_stem_kernel<3, true> : mbv2_stem_kernel<0, true>)
+                        : (form == 1 ? mbv2_stem_kernel<1, false> : form == 3 ? mbv2_stem_kernel<3, false> : mbv2_stem_kernel<0, false>);
     hipLaunchKernelGGL(fn, dim3((unsigned)blocks), dim3(256), 0, st, p);
     SSD_LAUNCH_CHECK();
     return SSD_OK;
