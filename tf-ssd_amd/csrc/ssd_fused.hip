@@ -616,7 +616,10 @@ __device__ __forceinline__ void stem_body(const StemParams& p, float* __restrict
             }
         }
     };
-    if (DMA && blockIdx.x < total_tiles) issue_patch(blockIdx.x, 0);
+    if (DMA && blockIdx.x < total_tiles) {
+        issue_patch(blockIdx.x, 0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the first tile's patch: landed before the loop's first barrier
+    }
     int it = 0;
     for (long tile = blockIdx.x; tile < total_tiles; tile += gridDim.x, ++it) {
         int b, oy0, ox0, iy0, ix0;
@@ -731,7 +734,8 @@ __device__ __forceinline__ void stem_body(const StemParams& p, float* __restrict
                 }
             }
         }
-        __syncthreads();
+        if constexpr (DMA) lds_barrier();      // LDS only: the next tile's patch copy stays in flight until the top of the loop
+        else __syncthreads();
 
         // ---- depthwise: thread = 4 channels x 4 consecutive columns (8 rows x 4 strips x 8 groups = 256)
         if (!(p.ablate & 2)) {
@@ -763,7 +767,8 @@ __device__ __forceinline__ void stem_body(const StemParams& p, float* __restrict
                 *reinterpret_cast<f32x4*>(D + (oy * kSTW + ox + t) * kSLD + c4) = v;
             }
         }
-        __syncthreads();
+        if constexpr (DMA) lds_barrier();      // LDS only: the next tile's patch copy stays in flight until the top of the loop
+        else __syncthreads();
 
         // ---- project 32 -> 16 on the MFMA: wave handles pixel tiles wave, wave + 4 (8 tiles of 16 px)
         const int frow = lane & 15, fk = (lane >> 4) * 4;
@@ -789,6 +794,11 @@ __device__ __forceinline__ void stem_body(const StemParams& p, float* __restrict
                 acc[q] = mmaN<NP ? NP : 1>(wpb, b, acc[q]);
             }
         }
+        // DMA form: the next tile's patch (issued at the top of this tile, a whole tile of work ago) must have LANDED before this wave
+        // reaches the barrier that opens the next tile -- waited for here, in front of this tile's stores, so that the wait does not
+        // include them (the LDS-only barriers above do not drain vmcnt; hipcc does not order `buffer_load ... lds` against a later
+        // __syncthreads() by itself: checked in the ISA)
+        if constexpr (DMA) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
             const int po = (wave + 4 * q) * 16 + (lane & 15);
