@@ -1,4 +1,5 @@
-"""Diagnostics (not a test): 300 pipelined steps on 6 different batches vs the one-at-a-time results, bitwise."""
+"""Diagnostics (not a test): 300 pipelined steps on 6 different batches, bitwise against the first pipelined pass over the same batches.
+usage: python tests/micro/lanes_stress.py [batch] [lanes]"""
 import os, sys
 sys.path[:0] = [os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))) + "/tf-ssd_amd"]
 import numpy as np, torch
@@ -12,9 +13,12 @@ pri = bbox_utils.generate_prior_boxes(hp["feature_map_shapes"], hp["aspect_ratio
 m = get_model(hp, max_batch=B)
 data_utils.synthetic_weights(m)
 xs = [h.to_dev(data_utils.synthetic_images(B, 300, seed=s)) for s in range(6)]
-dm = get_decoder_model(m, pri, hp, lanes=2)
-ref = [[t.clone() for t in dm(x)] for x in xs]
-torch.cuda.synchronize()
+dm = get_decoder_model(m, pri, hp, lanes=int(sys.argv[2]) if len(sys.argv) > 2 else 3)
+# reference = the lanes' own first results (since round 4 a lane replica splits the whole-image blocks over fewer channel groups than
+# the base model -- lanes_hint -- so dm(x), which runs the base model, differs in the last bits by design)
+first = [dm.submit(x) for x in xs]
+dm.wait(); torch.cuda.synchronize()
+ref = [[t.clone() for t in o] for o in first]
 bad = 0
 outs = []
 for i in range(300):
@@ -26,4 +30,4 @@ for i in range(300):
                 if not torch.equal(a, b):
                     bad += 1
         outs = []
-print("pipelined steps differing from the sequential result:", bad, "pair", dm.lane_calibration)
+print("pipelined steps differing from the first pipelined pass:", bad, "pair", dm.lane_calibration)
