@@ -1,7 +1,7 @@
 #!/bin/bash
 # run-to-run spread of the headline line (fresh process each): N x bench.py, value + lane check
 N=${1:-12}; shift
-OUT=gpurun_out/r4rep
+OUT=gpurun_out/${TAG:-rep}
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 for i in $(seq 1 $N); do
