@@ -87,9 +87,17 @@ def main():
                     help="f32 (default: the reference's arithmetic, BASELINE configs[1] / [2]) or bf16 (configs[3] / [4]: every matrix "
                          "operand of the dense / 1x1 convs rounded once to bf16, one bf16 MFMA per product, fp32 accumulation "
                          "and epilogues; activations stay fp32 in HBM)")
+    ap.add_argument("--inputs", type=int, default=4,
+                    help="distinct resident input batches rotated through the timed steps (config.inputs_rotated)")
     ap.add_argument("--repeats", type=int, default=5,
                     help="the K-step timed region is run this many times (barrier + synchronize around each); `value` / "
                          "`ms_per_step` come from the MEDIAN region, `timing_spread` reports min / median / max")
+    ap.add_argument("--other-configs", default="auto", choices=["auto", "on", "off"],
+                    help="after the headline (BASELINE configs[1]) also time the other single-GPU BASELINE configs -- VGG16 B=32 fp32 "
+                         "(configs[2]), the 512x512 B=16 shard in fp32 and bf16 (configs[4]), the training step B=32 in fp32 and bf16 "
+                         "(configs[3]), the MobileNetV2 B=64 step in bf16 and the reference's own batch 32 -- each in a fresh process "
+                         "(3 regions x >= 10 steps) and append them to the JSON line as `other_configs`; `value` stays configs[1].  "
+                         "auto = only for the default workload at N = 1")
     ap.add_argument("--force-dist", action="store_true",
                     help="take the N > 1 code paths at world size 1: RCCL communicator alive (init, first collective, barriers, "
                          "MAX-reduce of the time; --train: bucketed gradient all-reduce on the communication stream)")
@@ -169,7 +177,16 @@ def main():
     weights = data_utils.synthetic_weights(model, seed=1)
     priors = bbox_utils.generate_prior_boxes(hp["feature_map_shapes"], hp["aspect_ratios"])
     decoder_model = get_decoder_model(model, priors, hp, lanes=args.lanes)
-    x = ssd_hip.to_dev(data_utils.synthetic_images(B, hp["img_size"], seed=rank))   # resident in HBM
+    # ROTATE distinct resident batches through the timed steps (four by default): with one batch every lane would re-read the
+    # same 69 MB from the Infinity Cache step after step
+    n_inputs = max(1, args.inputs)
+    xs = [ssd_hip.to_dev(data_utils.synthetic_images(B, hp["img_size"], seed=rank + 1000 * k)) for k in range(n_inputs)]   # resident in HBM
+    x = xs[0]
+    step_no = [0]
+
+    def next_x():
+        step_no[0] += 1
+        return xs[step_no[0] % n_inputs]
 
     def barrier():
         if dist is not None:
@@ -182,11 +199,11 @@ def main():
     def run_steps(dm, n, lanes):
         if lanes > 1:
             for _ in range(n):
-                out = dm.submit(x, sync_input=False)        # x is resident and complete (contract: inputs in HBM)
+                out = dm.submit(next_x(), sync_input=False)        # resident and complete (contract: inputs in HBM)
             dm.wait()
         else:
             for _ in range(n):
-                out = dm(x)
+                out = dm(next_x())
         return out
 
     def region(dm, lanes):
@@ -307,7 +324,7 @@ def main():
     # ---- roofline leg: same K steps with per-layer hipEvents on the launch stream
     model.set_timing(True)
     for _ in range(args.steps):
-        decoder_model(x)
+        decoder_model(next_x())
     info, nfw = model.read_timing(B)
     model.set_timing(False)
     # the dense-conv family on the fp32 matrix cores: implicit-GEMM tiles and Winograd F(2x2,3x3) tiles
@@ -418,6 +435,8 @@ def main():
                        "" if (args.dtype == "bf16") == (hp["img_size"] != 300) else " shape, in %s" % args.dtype),
                    "global_batch": world * B, "priors": model.num_priors, "labels": hp["total_labels"],
                    "mean_detections_per_image": mean_det, "nms_active": mean_det > 0, "parallelism": "batch-sharded x%d, no collective" % world,
+                   "inputs_rotated": n_inputs, "results": "device-resident ([B,200,4] boxes, [B,200] labels / scores, [B] valid counts stay in HBM; the "
+                                                          "reference's predict() returns them as host arrays: 307 KB per 64-image step, not copied here)",
                    "batches_in_flight_per_gpu": args.lanes, "options": dict(getattr(model, "_options", {})),
                    "lane_calibration": getattr(decoder_model, "lane_calibration", None),
                    # where the kernel choices came from (tuning.py): a shipped table = nothing timed on the
@@ -486,7 +505,68 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(args.backbone, hp, weights, priors.cpu().numpy(), args.cpu_sample)
     decoder_model.close()
+    default_workload = (args.backbone == "mobilenet_v2" and hp["img_size"] == 300 and args.dtype == "f32" and B == 64
+                        and not args.opt and not args.no_overlap)
+    if rank == 0 and world == 1 and dist is None and (args.other_configs == "on" or (args.other_configs == "auto" and default_workload)):
+        del decoder_model, model, xs, x                   # the sub-runs get the whole device
+        torch.cuda.empty_cache()
+        result["other_configs"] = other_configs(args)
     emit(result, rank, dist)
+
+
+# The other single-GPU BASELINE.json configs, timed by the SAME invocation (the driver's command is fixed): each is this
+# script again in a fresh process (its own runtime setup: the training step keeps the runtime's default hardware queues),
+# 3 timed regions x >= 10 steps, no CPU leg.  `value` of the parent line stays configs[1].
+OTHER_CONFIGS = [
+    ("configs[2]: SSD300 VGG16 inference, batch 32, fp32", ["--backbone", "vgg16", "--batch", "32"]),
+    ("configs[4] per-GPU shard: SSD512 MobileNetV2 inference, batch 16, fp32 (the reference's arithmetic)", ["--img-size", "512", "--batch", "16"]),
+    ("configs[4] per-GPU shard: SSD512 MobileNetV2 inference, batch 16, bf16", ["--img-size", "512", "--batch", "16", "--dtype", "bf16"]),
+    ("configs[3] per-GPU shape: SSD300 MobileNetV2 training step, batch 32, fp32 (the reference's arithmetic)", ["--train", "--batch", "32"]),
+    ("configs[3] per-GPU shape: SSD300 MobileNetV2 training step, batch 32, bf16", ["--train", "--batch", "32", "--dtype", "bf16"]),
+    ("configs[1] shape in bf16: SSD300 MobileNetV2 inference, batch 64", ["--batch", "64", "--dtype", "bf16"]),
+    ("the reference's own batch (predictor.py:9): SSD300 MobileNetV2 inference, batch 32, fp32", ["--batch", "32"]),
+    ("configs[0] shape on the GPU: SSD300 MobileNetV2 inference, batch 1, fp32 (latency)", ["--batch", "1"]),
+]
+
+
+def other_configs(args):
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k != "GPU_MAX_HW_QUEUES"}       # each sub-run places its own
+    steps = max(10, args.steps // 2)
+    out = []
+    for label, extra in OTHER_CONFIGS:
+        cmd = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--steps", str(steps), "--warmup", "3", "--repeats", "3",
+               "--no-cpu-baseline", "--no-h2d", "--other-configs", "off"] + extra
+        t0 = time.perf_counter()
+        rec = {"workload": label, "args": " ".join(extra)}
+        try:
+            pr = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=240)
+            lines = [l for l in pr.stdout.splitlines() if l.startswith("{")]
+            if pr.returncode != 0 or not lines:
+                raise RuntimeError("rc %d: %s" % (pr.returncode, pr.stderr.strip()[-300:]))
+            r = json.loads(lines[-1])
+            ro = r.get("roofline") or {}
+            dk = ro.get("dominant_kernel") or {}
+            rec.update({
+                "dtype": r["dtype"], "ms_per_step": r["ms_per_step"], "images_per_sec": r["value"], "steps": r["steps"],
+                "timing_spread": r.get("timing_spread"),
+                "one_step_at_a_time_ms": (r.get("other_mode") or {}).get("ms_per_step"),
+                "roofline": {"kernel": ("%s %s" % (dk.get("layer"), dk.get("config"))) if dk else ro.get("kernel"),
+                             "achieved": dk.get("achieved", ro.get("achieved")), "peak": dk.get("peak", ro.get("peak")),
+                             "frac": dk.get("frac", ro.get("frac")), "unit": "TFLOP/s",
+                             "family_frac": ro.get("frac"), "family_achieved": ro.get("achieved"), "family_peak": ro.get("peak"),
+                             "frac_step_vs_fp32_mfma_peak": ro.get("frac_step_vs_fp32_mfma_peak", ro.get("frac_algorithmic_vs_fp32_mfma_peak"))},
+                "table_build": ((r.get("config") or {}).get("kernel_table") or {}).get("table_build"),
+                "kernel_table": (r.get("config") or {}).get("kernel_table"),
+                "build_id_from_sources": (r.get("config") or {}).get("build_id_from_sources"),
+                "mean_detections_per_image": (r.get("config") or {}).get("mean_detections_per_image"),
+                "loss_first_last": [(r.get("config") or {}).get("loss_first_step"), (r.get("config") or {}).get("loss_last_step")] if "--train" in extra else None,
+            })
+        except Exception as exc:                                  # never lose the headline over a sub-run
+            rec["error"] = repr(exc)[:400]
+        rec["wall_s"] = round(time.perf_counter() - t0, 2)
+        out.append(rec)
+    return out
 
 
 def train_bench(args, hp, get_model, rank, world, dist):

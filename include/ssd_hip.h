@@ -295,6 +295,11 @@ int ssd_net_set_tuning(ssd_net* net, const char* text);
  * across processes.  (The reference's Keras graph is deterministic in which kernels it runs; this is
  * the counterpart guarantee -- models/ssd_mobilenet_v2.py:7-35.) */
 int ssd_net_tuning_stats(const ssd_net* net, int* from_table, int* timed);
+/* Device memory a finalized net holds, bytes: out[0] activation arena (one fp32 slot per tensor x max_batch), out[1] bf16
+ * planes of the activations its CHOSEN LDS-DMA conv tiles read (allocated for the finalize-time race, freed again where
+ * no chosen tile reads them), out[2] partial-sum slabs of the whole-image block kernel, out[3] split-K slabs.  A lane
+ * replica (models/decoder.py) holds the same again. */
+int ssd_net_memory_bytes(const ssd_net* net, size_t out[4]);
 /* sha256 (first 16 hex digits) of the kernel sources this library was built from (csrc/build.sh);
  * shipped tuning tables record the build they were measured on. */
 const char* ssd_build_id(void);

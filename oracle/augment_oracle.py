@@ -7,6 +7,13 @@ imported here and the reference ships no fixtures, so the TF image ops are resta
 here (the reference draws them with ``tf.random.uniform`` / ``sample_distorted_bounding_box``): given the same draws,
 every function is deterministic -- that is what the HIP kernels are held to.
 
+The colour ops in particular: TF 2.0 dispatches ``tf.image.adjust_hue`` / ``adjust_saturation`` / ``adjust_contrast`` to its
+FUSED C++ kernels (``AdjustHue``, ``AdjustSaturation``, ``AdjustContrastv2``), each with its own operation order (the hue /
+saturation kernels convert RGB -> HSV -> RGB per pixel in one pass; ``AdjustContrastv2`` computes the per-channel mean in
+float and applies ``(x - mean) * factor + mean``).  The plain HSV path below restates their published semantics, not their
+instruction order: agreement with a real TF trace is expected to the last few ulps, not bitwise, and stays unpinned until
+``tools/make_tf_golden.py`` can run.
+
 Images: float32 [H,W,3] in [0,1] (the reference augments AFTER convert + resize, utils/data_utils.py:22-26).
 Boxes: float32 [G,4] = (y1, x1, y2, x2) normalised."""
 import numpy as np
@@ -194,14 +201,22 @@ def color(img, brightness=None, contrast=None, hue=None, saturation=None):
     return np.clip(x, F32(0), F32(1)).astype(F32)
 
 
-def satisfies_overlap(window, gt_boxes, min_object_covered):
-    """[3P] SampleDistortedBoundingBox's acceptance test: some ground-truth box has at least ``min_object_covered`` of
-    its area inside the window (normalised coordinates)."""
-    g = np.asarray(gt_boxes, np.float64)
-    if g.size == 0:
-        return True
-    iy = np.clip(np.minimum(g[:, 2], window[2]) - np.maximum(g[:, 0], window[0]), 0, None)
-    ix = np.clip(np.minimum(g[:, 3], window[3]) - np.maximum(g[:, 1], window[1]), 0, None)
-    area = (g[:, 2] - g[:, 0]) * (g[:, 3] - g[:, 1])
-    ok = area > 0
-    return bool(((iy * ix)[ok] / area[ok] >= min_object_covered).any()) if ok.any() else False
+def satisfies_overlap(window, gt_boxes, min_object_covered, height, width):
+    """[3P] SampleDistortedBoundingBox's acceptance test (``SatisfiesOverlapConstraints`` of the TF 2.0 kernel): window
+    (y1, x1, y2, x2) in PIXELS, ground-truth boxes normalised; the kernel truncates the boxes to integer pixel rectangles
+    first; boxes (or a window) without a single pixel never satisfy; some box with >= ``min_object_covered`` of its pixel
+    area inside the window does."""
+    g = np.asarray(gt_boxes, np.float64).reshape(-1, 4)
+    wy1, wx1, wy2, wx2 = [int(v) for v in window]
+    if (wy2 - wy1) * (wx2 - wx1) < 1:
+        return False
+    for y1, x1, y2, x2 in g:
+        by1, bx1, by2, bx2 = int(y1 * height), int(x1 * width), int(y2 * height), int(x2 * width)
+        area = (by2 - by1) * (bx2 - bx1)
+        if area < 1:
+            continue
+        ih = max(0, min(by2, wy2) - max(by1, wy1))
+        iw = max(0, min(bx2, wx2) - max(bx1, wx1))
+        if np.float32(ih * iw) / np.float32(area) >= np.float32(min_object_covered):
+            return True
+    return False

@@ -4,8 +4,9 @@ import sys
 import pytest
 
 # The suite runs on the HIP runtime's own default of four hardware queues (hipGraph replay, the calibrated two-lane
-# path and the side streams are all covered there); the package's serving default (three queues for three lanes,
-# ssd_hip._default_hw_queues) is tested in a subprocess of its own (test_default_serving_setup*).
+# path and the side streams are all covered there); the serving opt-in (three queues for three lanes,
+# ssd_hip.configure_serving) is tested in subprocesses of its own (test_default_serving_setup*,
+# test_full_size_c2_under_the_serving_queue_setup).
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "4")
 
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

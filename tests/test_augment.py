@@ -66,8 +66,9 @@ def test_oracle_colour_known_answers():
     np.testing.assert_allclose(ao.adjust_brightness(px, 0.1), px + F32(0.1))
     c = ao.color(px, brightness=0.9)
     assert c.max() <= 1.0 and c.min() >= 0.0
-    assert ao.satisfies_overlap(np.array([0.0, 0.0, 0.5, 0.5]), np.array([[0.0, 0.0, 0.4, 0.4]]), 0.9)
-    assert not ao.satisfies_overlap(np.array([0.0, 0.0, 0.2, 0.2]), np.array([[0.0, 0.0, 0.4, 0.4]]), 0.3)      # 25 % covered
+    assert ao.satisfies_overlap((0, 0, 50, 50), np.array([[0.0, 0.0, 0.4, 0.4]]), 0.9, 100, 100)
+    assert not ao.satisfies_overlap((0, 0, 20, 20), np.array([[0.0, 0.0, 0.4, 0.4]]), 0.3, 100, 100)      # 25 % covered
+    assert ao.satisfies_overlap((0, 0, 20, 20), np.array([[0.0, 0.0, 0.4, 0.4]]), 0.25, 100, 100)          # exactly 25 %
 
 
 # ---------------------------------------------------------------------------------------------------------- GPU: kernels
@@ -171,7 +172,7 @@ def test_apply_batch_invariants_and_padding():
             y, x, hh, ww = aug.sample_distorted_bounding_box(120, 160, g, mo)
             assert 0 <= y and 0 <= x and y + hh <= 120 and x + ww <= 160 and hh > 0 and ww > 0
             whole = (y, x, hh, ww) == (0, 0, 120, 160)
-            assert whole or aug.window_satisfies(np.array([y / 120, x / 160, (y + hh) / 120, (x + ww) / 160]), g, mo)
+            assert whole or aug.window_satisfies((y, x, y + hh, x + ww), aug.pixel_rectangles(g, 120, 160), mo)
             assert whole or (0.5 - 0.05 <= ww / hh <= 2.0 + 0.05 and hh * ww >= 0.05 * 120 * 160 - 1)
 
 

@@ -246,6 +246,11 @@ def test_nets_on_lds_dma_tiles(backbone, prec, B):
     m.set_tuning("\n".join(lines) + "\n")
     d1, p1 = [_np(t) for t in m(x)]
     ran = [r for r in m.layers(B) if r["config"].startswith(dst) and r["flops"] > 0]
+    # the planes are allocated for finalize's race and kept only where a CHOSEN tile reads them
+    mem0, mem1 = ref.memory_summary(), m.memory_summary()
+    assert mem0["planes"] == 0 and mem0["arena"] == mem1["arena"] > 0
+    n_dma_inputs = len({r["name"] for r in m.layers(B) if r["config"].startswith(dst)})
+    assert 0 < mem1["planes"] <= (3 if prec == "fp32" else 1) * mem1["arena"] // 2 + 512 * n_dma_inputs, (mem0, mem1)
     # (a swapped line whose layer has Cin % 32 != 0 -- or % 64 in the bf16 form -- falls back to the autotune: fine)
     # (MobileNetV2's dense convs outside the fused blocks are few: Conv_1, the extras, the heads)
     assert len(ran) >= (1 if backbone == "mobilenet_v2" else 3), "too few layers ran on %s* tiles: %s" % (dst, [r["config"] for r in m.layers(B)])

@@ -407,19 +407,24 @@ def test_shipped_kernel_tables_were_measured_at_this_build():
     assert not stale, "tables measured at another build than %s (re-run tools/make_tuning_tables.py): %s" % (want, stale[:4])
 
 
-def test_default_serving_setup_is_placed_before_the_runtime_starts():
-    """The measured serving setup (three in-order lanes on three hardware queues) is what a drop-in user gets without
-    setting anything: importing ``ssd_hip`` places GPU_MAX_HW_QUEUES=3 before torch / the HIP runtime start, unless the
-    process already chose a value or opts out; ``get_decoder_model`` then defaults to that many lanes in auto mode."""
+def test_serving_setup_is_an_explicit_opt_in_placed_before_the_runtime_starts():
+    """importing the package must not change the process environment.  The measured serving setup (three
+    in-order lanes on three hardware queues) is an explicit opt-in -- ``ssd_hip.configure_serving()`` (what ``predictor.py``
+    and ``bench.py`` call first thing) or SSD_HIP_HW_QUEUES=3 -- placed before torch / the HIP runtime start, and never
+    overrides a value the process already chose; ``get_decoder_model`` defaults to that many lanes in auto mode."""
     pkg = os.path.join(REPO, "tf-ssd_amd")
-    code = ("import os, sys; sys.path.insert(0, %r); import ssd_hip; from models import decoder; "
-            "print(os.environ.get('GPU_MAX_HW_QUEUES'), decoder.default_lanes())" % pkg)
+    code = ("import os, sys; sys.path.insert(0, %r); import ssd_hip; %s; from models import decoder; "
+            "print(os.environ.get('GPU_MAX_HW_QUEUES'), decoder.default_lanes())")
     base = {k: v for k, v in os.environ.items() if k not in ("GPU_MAX_HW_QUEUES", "SSD_HIP_HW_QUEUES", "SSD_HIP_LANES")}
-    run = lambda env: subprocess.check_output([sys.executable, "-c", code], env=env, text=True).split()
-    assert run(base) == ["3", "3"]
-    assert run(dict(base, GPU_MAX_HW_QUEUES="8")) == ["8", "1"]             # the process chose: left alone
+    run = lambda env, call="pass": subprocess.check_output([sys.executable, "-c", code % (pkg, call)], env=env, text=True).split()
+    assert run(base) == ["None", "1"]                                       # a plain import leaves the environment alone
+    assert run(base, "assert ssd_hip.configure_serving()") == ["3", "3"]
+    assert run(base, "assert ssd_hip.configure_serving(2)") == ["2", "2"]
+    assert run(dict(base, SSD_HIP_HW_QUEUES="3")) == ["3", "3"]             # the same opt-in through the environment
+    assert run(dict(base, GPU_MAX_HW_QUEUES="8"), "assert not ssd_hip.configure_serving()") == ["8", "1"]   # the process chose: left alone
     assert run(dict(base, GPU_MAX_HW_QUEUES="2")) == ["2", "2"]
-    assert run(dict(base, SSD_HIP_HW_QUEUES="runtime")) == ["None", "1"]    # opt-out: the runtime's own default
+    src = open(os.path.join(pkg, "predictor.py")).read()
+    assert src.index("ssd_hip.configure_serving()") < src.index("from utils import")
 
 
 _RANKS_WORKER = '''
@@ -479,8 +484,20 @@ def test_augmentation_host_logic_vs_oracle():
         for _ in range(30):
             y, x, hh, ww = aug.sample_distorted_bounding_box(200, 300, g, mo)
             assert 0 <= y and 0 <= x and 0 < hh and 0 < ww and y + hh <= 200 and x + ww <= 300
-            win = np.array([y / 200, x / 300, (y + hh) / 200, (x + ww) / 300])
-            assert (y, x, hh, ww) == (0, 0, 200, 300) or ao.satisfies_overlap(win, g, mo)
+            assert y + hh < 200 or hh == 200, "Uniform(n) is exclusive: the last offset is never drawn"
+            assert (y, x, hh, ww) == (0, 0, 200, 300) or ao.satisfies_overlap((y, x, y + hh, x + ww), g, mo, 200, 300)
+    with pytest.raises(ValueError):
+        aug.sample_distorted_bounding_box(200, 300, np.zeros((0, 4), np.float32), 0.5)       # TF raises on an empty list
+    # zero-area padding rows never satisfy; a window without a pixel never does
+    assert not ao.satisfies_overlap((0, 0, 200, 300), np.zeros((3, 4), np.float32), 0.1, 200, 300)
+    assert not aug.window_satisfies((0, 0, 200, 300), aug.pixel_rectangles(np.zeros((3, 4), np.float32), 200, 300), 0.1)
+    assert aug.sample_distorted_bounding_box(200, 300, np.zeros((3, 4), np.float32), 0.1) == (0, 0, 200, 300)
+    # integer pixel rectangles: a box of 0.9 pixels (truncates to zero area) is skipped, one of exactly one pixel counts
+    tiny = np.array([[0.5, 0.5, 0.5 + 0.9 / 200, 0.5 + 0.9 / 300]], np.float32)
+    one = np.array([[0.5, 0.5, 0.5 + 1.01 / 200, 0.5 + 1.01 / 300]], np.float32)
+    for box, want in ((tiny, False), (one, True)):
+        assert ao.satisfies_overlap((90, 140, 110, 160), box, 0.5, 200, 300) is want
+        assert aug.window_satisfies((90, 140, 110, 160), aug.pixel_rectangles(box, 200, 300), 0.5) is want
     aug.seed(1)
     a = [aug.get_random_bool() for _ in range(400)]
     assert 120 < sum(a) < 280

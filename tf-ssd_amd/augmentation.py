@@ -186,16 +186,21 @@ def sample_distorted_bounding_box(height, width, gt_boxes, min_object_covered, a
     (begin_y, begin_x, size_h, size_w)."""
     g = _boxes(gt_boxes).astype(np.float64)
     H, W = int(height), int(width)
+    if g.shape[0] == 0:             # the TF op with use_image_if_no_bounding_boxes=False (the reference's call) raises
+        raise ValueError("sample_distorted_bounding_box: no bounding boxes provided as input")
+    rects = pixel_rectangles(g, H, W)
     min_area, max_area = area_range[0] * H * W, area_range[1] * H * W
     for _ in range(max_attempts):
         aspect = _rng.uniform(aspect_ratio_range[0], aspect_ratio_range[1])
         min_h = int(np.rint(np.sqrt(min_area / aspect)))
         max_h = int(np.rint(np.sqrt(max_area / aspect)))
         if int(np.rint(max_h * aspect)) > W:
-            max_h = int((W + 0.5 - 1e-7) / aspect)
+            max_h = int((W + 0.5 - 1e-7) / aspect)          # the largest height whose rounded width still fits ...
+            if int(np.rint(max_h * aspect)) > W:
+                max_h -= 1                                  # ... and the kernel's fallback when the rounding disagrees
         max_h = min(max_h, H)
         min_h = min(min_h, max_h)
-        h = min_h + int(_rng.integers(0, max_h - min_h + 1)) if min_h < max_h else min_h
+        h = min_h + int(_rng.integers(0, max_h - min_h + 1)) if min_h < max_h else min_h     # closed range, as in the kernel
         w = int(np.rint(h * aspect))
         if w * h < min_area:
             h += 1
@@ -205,23 +210,33 @@ def sample_distorted_bounding_box(height, width, gt_boxes, min_object_covered, a
             w = int(np.rint(h * aspect))
         if w * h < min_area or w * h > max_area or w > W or h > H or w <= 0 or h <= 0:
             continue
-        y = int(_rng.integers(0, H - h + 1)) if h < H else 0
-        x = int(_rng.integers(0, W - w + 1)) if w < W else 0
-        if window_satisfies(np.array([y / H, x / W, (y + h) / H, (x + w) / W]), g, min_object_covered):
+        y = int(_rng.integers(0, H - h)) if h < H else 0     # random->Uniform(n) draws from [0, n): the last offset is never taken
+        x = int(_rng.integers(0, W - w)) if w < W else 0
+        if window_satisfies((y, x, y + h, x + w), rects, min_object_covered):
             return y, x, h, w
     return 0, 0, H, W
 
 
-def window_satisfies(window, gt_boxes, min_object_covered):
-    """The acceptance rule of the sampler: some box has >= min_object_covered of its area inside the window."""
-    g = np.asarray(gt_boxes, np.float64)
-    if g.size == 0:
-        return True
-    iy = np.clip(np.minimum(g[:, 2], window[2]) - np.maximum(g[:, 0], window[0]), 0, None)
-    ix = np.clip(np.minimum(g[:, 3], window[3]) - np.maximum(g[:, 1], window[1]), 0, None)
-    area = (g[:, 2] - g[:, 0]) * (g[:, 3] - g[:, 1])
-    ok = area > 0
-    return bool(((iy * ix)[ok] / area[ok] >= min_object_covered).any()) if ok.any() else False
+def pixel_rectangles(gt_boxes, height, width):
+    """Normalised [y1, x1, y2, x2] boxes as the kernel's integer pixel rectangles (truncation towards zero)."""
+    g = np.asarray(gt_boxes, np.float64).reshape(-1, 4)
+    return np.stack([np.trunc(g[:, 0] * height), np.trunc(g[:, 1] * width), np.trunc(g[:, 2] * height), np.trunc(g[:, 3] * width)],
+                    axis=1).astype(np.int64)
+
+
+def window_satisfies(window, rects, min_object_covered):
+    """The acceptance rule of the sampler (``SatisfiesOverlapConstraints``), on INTEGER pixel rectangles like the kernel:
+    the window holds at least one pixel and some box of at least one pixel has >= min_object_covered of its area inside it
+    (boxes without a pixel -- the zero padding of a batch -- are skipped)."""
+    r = np.asarray(rects, np.int64).reshape(-1, 4)
+    wy1, wx1, wy2, wx2 = [int(v) for v in window]
+    if (wy2 - wy1) * (wx2 - wx1) < 1:
+        return False
+    iy = np.clip(np.minimum(r[:, 2], wy2) - np.maximum(r[:, 0], wy1), 0, None)
+    ix = np.clip(np.minimum(r[:, 3], wx2) - np.maximum(r[:, 1], wx1), 0, None)
+    area = (r[:, 2] - r[:, 0]) * (r[:, 3] - r[:, 1])
+    ok = area >= 1
+    return bool(((iy * ix)[ok].astype(np.float32) / area[ok].astype(np.float32) >= np.float32(min_object_covered)).any()) if ok.any() else False
 
 
 def patch(img, gt_boxes, draws=None):

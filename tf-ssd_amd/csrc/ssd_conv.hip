@@ -473,6 +473,9 @@ int launch_splitk_reduce(const ConvParams& p, hipStream_t st) {
     if (vec) hipLaunchKernelGGL(splitk_reduce_kernel<4>, dim3(blocks), dim3(256), 0, st, p);
     else hipLaunchKernelGGL(splitk_reduce_kernel<1>, dim3(blocks), dim3(256), 0, st, p);
     SSD_LAUNCH_CHECK();
+    // only the 4-wide form writes the output's bf16 planes: on the scalar path (an unaligned caller workspace) they come
+    // from a pass of their own, never silently stale
+    if (!vec && p.op && p.out) return launch_split_planes(p.out, p.M * p.Cout, p.Cout, p.op_np, p.op, p.op_plane, st);
     return SSD_OK;
 }
 

@@ -211,7 +211,10 @@ __device__ __forceinline__ void conv_dma_body(const ConvParams& p, char* __restr
         ns_cur = steps_here();
         issue(0);
     }
-    __syncthreads();                 // (s_waitcnt vmcnt(0) + s_barrier: the DMA counts on vmcnt)
+    // the first tile's LDS-DMA has to have LANDED before any wave reads it: the copies count on vmcnt, and nothing in the
+    // workgroup-barrier contract makes hipcc drain vmcnt for them (ROCm 7.2 happens to) -- wait explicitly, as the stem does
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
     for (int kt = kt_begin; kt < kt_end; ++kt) {
         const int stage = (kt - kt_begin) & 1;
         int ns_next = 1;
@@ -222,6 +225,7 @@ __device__ __forceinline__ void conv_dma_body(const ConvParams& p, char* __restr
         }
         mma_tile(stage, ns_cur);
         ns_cur = ns_next;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the next tile's copies, before the barrier that publishes them
         __syncthreads();
     }
     conv_epilogue<MT, NT>(p, acc, m0, n0, wm, wn, lane, HoWo);

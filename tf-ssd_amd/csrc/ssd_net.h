@@ -110,6 +110,7 @@ struct ssd_net {
     int last_batch = 0;
     std::vector<float*> owned;      // device allocations to free
     float* arena = nullptr;
+    size_t arena_bytes = 0, plane_bytes = 0, slab_bytes = 0;    // ssd_net_memory_bytes
     float* splitk_ws = nullptr;
     size_t splitk_floats = 0;
     // predict() scratch

@@ -999,6 +999,7 @@ int ssd_net_finalize(ssd_net* net, int max_batch) {
         }
         net->img_slabs = nullptr;
         net->img_tickets = nullptr;
+        net->slab_bytes = slab * sizeof(float);
         if (slab) {
             float* tk = nullptr;
             int rc = dev_alloc(*net, slab, &net->img_slabs);
@@ -1090,6 +1091,26 @@ int ssd_net_finalize(ssd_net* net, int max_batch) {
     net->n_preset = n_preset;
     if (n_tuned) rc = autotune(*net, max_batch, st);
     if (rc) return rc;
+    // the planes were allocated for the race; keep them only where a CHOSEN tile reads them (6 bytes per element in fp32 nets,
+    // 2 in the bf16 mode, on top of the fp32 slot: a table without LDS-DMA tiles leaves none)
+    {
+        std::vector<char> read(net->tensors.size(), 0);
+        for (const auto& l : net->layers)
+            if (l.kind == LK_CONV && l.in >= 0 && conv_config_is_dma(l.cfg)) read[l.in] = 1;
+        SSD_HIP(hipStreamSynchronize(st));
+        net->plane_bytes = 0;
+        net->arena_bytes = total * sizeof(float);
+        for (size_t i = 0; i < net->tensors.size(); ++i) {
+            Tensor& t = net->tensors[i];
+            if (!t.planes) continue;
+            const size_t bytes = ((size_t)t.planes_np * t.plane_stride / 2 + 64) * sizeof(float);
+            if (read[i]) { net->plane_bytes += bytes; continue; }
+            float* pl = reinterpret_cast<float*>(t.planes);
+            net->owned.erase(std::remove(net->owned.begin(), net->owned.end(), pl), net->owned.end());
+            (void)hipFree(pl);
+            t.planes = nullptr; t.planes_np = 0; t.plane_stride = 0;
+        }
+    }
     // every split-K layer gets its own slab (layers on different streams may overlap)
     {
         if (net->splitk_layers) (void)hipFree(net->splitk_layers);
@@ -1152,6 +1173,21 @@ long ssd_net_get_tuning(const ssd_net* net, char* buf, size_t cap) {
         out += std::string("__launch graph ") + (net->use_graph ? "1" : "0") + "\n";
     if (buf && cap > out.size()) memcpy(buf, out.c_str(), out.size() + 1);
     return (long)out.size();
+}
+
+// device memory the finalized net holds, in bytes: [0] activation arena, [1] bf16 planes of the activations its chosen LDS-DMA
+// tiles read, [2] whole-image kernel slabs, [3] split-K slabs
+int ssd_net_memory_bytes(const ssd_net* net, size_t out[4]) {
+    SSD_CHECK_ARG(net != nullptr && out != nullptr, "ssd_net_memory_bytes: NULL argument");
+    SSD_CHECK_ARG(net->finalized, "ssd_net_memory_bytes: net is not finalized");
+    out[0] = net->arena_bytes;
+    out[1] = net->plane_bytes;
+    out[2] = net->slab_bytes;
+    size_t sk = net->splitk_floats;
+    for (const auto& l : net->layers)
+        if (l.kind == LK_CONV && l.split_k > 1) sk += align_up((size_t)l.split_k * net->max_batch * l.Ho * l.Wo * l.Cout, 64);
+    out[3] = sk * sizeof(float);
+    return SSD_OK;
 }
 
 int ssd_net_tuning_stats(const ssd_net* net, int* from_table, int* timed) {

@@ -244,6 +244,14 @@ class SSDModel(object):
                 f.write(tuning.with_header(table, key=key, build=lib.ssd_build_id().decode()))
             os.replace(tmp, path)
 
+    def memory_summary(self):
+        """Device bytes the finalized net holds (``ssd_net_memory_bytes``): activation arena, the bf16 planes its chosen
+        LDS-DMA tiles read (none where the table names no such tile), whole-image slabs, split-K slabs.  Every lane
+        replica of ``get_decoder_model(..., lanes=n)`` holds the same again."""
+        out = (ctypes.c_size_t * 4)()
+        _h.check(_h.lib().ssd_net_memory_bytes(self._net, out), "ssd_net_memory_bytes")
+        return {"arena": int(out[0]), "planes": int(out[1]), "image_slabs": int(out[2]), "splitk_slabs": int(out[3])}
+
     def set_tuning(self, text):
         """Pin the kernel choices (a table from ``get_tuning()`` of another instance, or a file): the next
         finalize uses it instead of the shipped table / autotune.  ``None`` returns to the default."""

@@ -425,8 +425,8 @@ class DecoderModel(object):
 
 def default_lanes():
     """Batches ``predict`` keeps in flight when the caller does not say: as many as the HIP runtime has hardware
-    queues when that number was limited to 2 or 3 (GPU_MAX_HW_QUEUES; ``ssd_hip`` sets 3 before the runtime starts
-    unless the process chose otherwise) -- every lane then owns a queue (section 5 of DESIGN.md: 3 lanes / 3 queues
+    queues when that number was limited to 2 or 3 (GPU_MAX_HW_QUEUES; ``ssd_hip.configure_serving()`` -- called by
+    ``predictor.py`` and ``bench.py`` -- or SSD_HIP_HW_QUEUES=3 place 3 before the runtime starts; importing the package alone does not) -- every lane then owns a queue (section 5 of DESIGN.md: 3 lanes / 3 queues
     50 k images/sec against 41 k one step at a time at B=64) -- else 1."""
     import os
     q = os.environ.get("GPU_MAX_HW_QUEUES", "")

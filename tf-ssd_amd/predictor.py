@@ -18,6 +18,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 if _HERE not in sys.path:
     sys.path.insert(0, _HERE)
 
+import ssd_hip  # noqa: E402
+ssd_hip.configure_serving()        # the serving entry point opts in to three lanes / three hardware queues before the runtime starts
 from utils import bbox_utils, data_utils, eval_utils, io_utils, train_utils  # noqa: E402
 from models.decoder import get_decoder_model  # noqa: E402
 

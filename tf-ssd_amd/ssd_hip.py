@@ -9,25 +9,31 @@ import os
 import sys
 
 
-def _default_hw_queues():
-    """The measured serving setup needs the HIP runtime limited to as many hardware queues as there
-    are lanes: three in-order lanes on three queues.  The runtime reads GPU_MAX_HW_QUEUES when it starts, so the default
-    is placed HERE, before this module imports torch -- unless the process already chose (the variable is set), opts out
-    (SSD_HIP_HW_QUEUES=runtime keeps the runtime's own default) or the runtime is already up (then it is too late and
-    ``models.decoder.default_lanes()`` answers 1)."""
-    want = os.environ.get("SSD_HIP_HW_QUEUES", "3")
-    if "GPU_MAX_HW_QUEUES" in os.environ or want in ("runtime", "0", ""):
-        return
+def configure_serving(lanes=3):
+    """OPT IN to the measured serving setup: ``lanes`` in-order lanes, each on its own hardware queue,
+    i.e. the HIP runtime limited to that many queues.  The runtime reads GPU_MAX_HW_QUEUES when it starts, so this has to
+    run before the first device call of the process (``predictor.py`` and ``bench.py`` do it first thing); it changes
+    nothing when the process already chose a value, and answers False when the runtime is already up (too late: one
+    lane is used, ``models.decoder.default_lanes()`` answers 1).  Process-wide consequences, which is why importing the
+    package no longer does this on its own (round 6): EVERY HIP stream of the process then shares ``lanes`` queues (a
+    training step's main / weight-gradient / RCCL streams included), hipGraph replay of the forked one-at-a-time step is off
+    below four queues, and ``get_decoder_model`` builds ``lanes`` replicas of the net (arena + bf16 planes each) once a
+    ``predict`` call is long enough to use them."""
+    if "GPU_MAX_HW_QUEUES" in os.environ:
+        return os.environ["GPU_MAX_HW_QUEUES"] == str(lanes)
     t = sys.modules.get("torch")
     try:
         if t is not None and t.cuda.is_initialized():
-            return
+            return False
     except Exception:
-        return
-    os.environ["GPU_MAX_HW_QUEUES"] = want
+        return False
+    os.environ["GPU_MAX_HW_QUEUES"] = str(int(lanes))
+    return True
 
 
-_default_hw_queues()
+# the same opt-in through the environment: SSD_HIP_HW_QUEUES=<n> (nothing is touched when it is unset)
+if os.environ.get("SSD_HIP_HW_QUEUES", "").isdigit() and int(os.environ["SSD_HIP_HW_QUEUES"]) > 0:
+    configure_serving(int(os.environ["SSD_HIP_HW_QUEUES"]))
 
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
@@ -110,6 +116,7 @@ _SIGNATURES = {
     "ssd_net_get_tuning": (ctypes.c_long, [vp, ctypes.c_char_p, ctypes.c_size_t]),
     "ssd_net_set_tuning": (ctypes.c_int, [vp, ctypes.c_char_p]),
     "ssd_net_tuning_stats": (ctypes.c_int, [vp, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int)]),
+    "ssd_net_memory_bytes": (ctypes.c_int, [vp, ctypes.POINTER(ctypes.c_size_t)]),
     "ssd_build_id": (ctypes.c_char_p, []),
     "ssd_stream_create": (vp, [ctypes.c_int]),
     "ssd_stream_create_masked": (vp, [ctypes.POINTER(ctypes.c_uint), ctypes.c_int]),
