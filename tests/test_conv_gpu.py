@@ -734,9 +734,13 @@ def test_image_block_kernel_vs_layer_kernels(B, ticket):
         np.testing.assert_array_equal(m.fetch_activation(n), got[n])
 
 
-@pytest.mark.parametrize("B", [3, 64])
-def test_image_block_split_form_vs_layer_kernels(B):
-    """The whole-image kernel's split-bf16 form (img_choice 2: both 1x1 convolutions as exact three-way bf16 splits,
+@pytest.mark.parametrize("B,second", [(3, 1), (3, 0), (24, 1), (64, 1), (64, 0), (232, 1)])
+def test_image_block_split_form_vs_layer_kernels(B, second):
+    """(``second`` = option image_v2: the kernel's second form, csrc/ssd_imgblock2.hip -- compile-time geometry, adjacent
+    pixels per lane, LDS-DMA weight chunks, chunk pairs dealt unevenly over the groups: B = 3 / 24 give 12 / 8 groups of
+    2 - 4 pairs, B = 232 the direct one-group epilogue with the residual -- or the first form for every block; block 13,
+    stride 2, keeps the first form either way.)
+    The whole-image kernel's split-bf16 form (img_choice 2: both 1x1 convolutions as exact three-way bf16 splits,
     six v_mfma_f32_16x16x32_bf16 per product, fp32 results; weights staged through LDS) pinned on every block it can
     run -- the finalize-time race only keeps it where it wins -- against the layer kernels, to the fp32 kernels' own
     tolerance; the table line reads back as "image 2" and the layer reports "image_split"."""
@@ -748,6 +752,7 @@ def test_image_block_split_form_vs_layer_kernels(B):
         x = np.concatenate([x] * ((B + 7) // 8))[:B] * np.linspace(0.5, 1.0, B, dtype=np.float32)[:, None, None, None]
     m = get_model(hp, max_batch=B)
     m.set_weights(w)
+    m.set_option("image_v2", second)
     names = ["block_%d_out" % k for k in range(7, 17)] + ["block_13_expand_relu"]
     m.set_option("fuse_image", 0)
     d0, p0 = m(x)

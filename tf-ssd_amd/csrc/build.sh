@@ -32,7 +32,7 @@ compile ssd_bbox.hip -ffp-contract=off -fhip-fp32-correctly-rounded-divide-sqrt
 # loss: separately rounded ops too (the hard-negative RANK depends on the per-anchor CE values)
 compile ssd_loss.hip -ffp-contract=off -fhip-fp32-correctly-rounded-divide-sqrt
 compile ssd_data.hip -ffp-contract=off -fhip-fp32-correctly-rounded-divide-sqrt
-for s in ssd_conv.hip ssd_conv3.hip ssd_convdma.hip ssd_wino.hip ssd_skinny.hip ssd_ops.hip ssd_fused.hip ssd_bandblock.hip ssd_band3.hip ssd_imgblock.hip ssd_dwproj.hip ssd_net.hip ssd_train.hip; do
+for s in ssd_conv.hip ssd_conv3.hip ssd_convdma.hip ssd_wino.hip ssd_skinny.hip ssd_ops.hip ssd_fused.hip ssd_bandblock.hip ssd_band3.hip ssd_imgblock.hip ssd_imgblock2.hip ssd_dwproj.hip ssd_net.hip ssd_train.hip; do
   [ -f "$s" ] && compile "$s"
 done
 wait

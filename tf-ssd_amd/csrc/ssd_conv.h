@@ -78,6 +78,7 @@ struct FusedBlockParams {
     short* e_planes;
     long e_plane;
     int planes_np;
+    int form2;                  // whole-image kernel: 1 = take the second form (csrc/ssd_imgblock2.hip) where it has a configuration
     long long* dbg;             // optional per-phase cycle counters [blocks][8] (profiling builds)
     int ablate;                 // diagnostics: 1 skip expand MFMAs, 2 skip depthwise math, 4 skip project MFMAs, 8 skip expand epilogue math
 };
@@ -116,6 +117,8 @@ bool dwproj_supported(const DwProjParams& p);
 int launch_dwproj(DwProjParams p, hipStream_t st);
 bool stem_supported(const StemParams& p);
 int launch_stem(StemParams p, hipStream_t st);
+bool image_block2_supported(const FusedBlockParams& p);
+int launch_image_block2(FusedBlockParams p, hipStream_t st);
 bool fused_block_supported(const FusedBlockParams& p);
 int launch_fused_block(FusedBlockParams p, hipStream_t st);
 bool band3_block_supported(const FusedBlockParams& p);

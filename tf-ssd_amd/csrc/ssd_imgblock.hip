@@ -841,13 +841,20 @@ int launch_image_block(FusedBlockParams p, hipStream_t st) {
     SSD_CHECK_ARG(!p.bf16 || (p.we3 && p.wp3), "image block: the bf16 form needs the weights' bf16 planes");
     SSD_CHECK_ARG(!p.bf16 || !p.tickets, "image block: the bf16 form combines by the second launch only");
     const image_kernel_t fn = p.bf16 == 3 ? c->fn3 : p.bf16 ? c->fn16 : c->fn;
-    if (lds > 64 * 1024)
+    const bool second = p.form2 && p.bf16 && !p.tickets && !p.ablate && image_block2_supported(p);
+    if (second) {
+        const int rc = launch_image_block2(p, st);
+        if (rc) return rc;
+    }
+    if (lds > 64 * 1024 && !second)
         SSD_HIP(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     // groups > 1: p.tickets == nullptr (default) combines the group slabs in a second launch -- the
     // launch boundary publishes them and every CU takes part (B=64: 43 us per block 7 instead of 46);
     // with tickets the last arriving group of each image combines inside the launch.
-    hipLaunchKernelGGL(fn, dim3((unsigned)((long)p.B * p.groups)), dim3(kIThreads), lds, st, p);
-    SSD_LAUNCH_CHECK();
+    if (!second) {
+        hipLaunchKernelGGL(fn, dim3((unsigned)((long)p.B * p.groups)), dim3(kIThreads), lds, st, p);
+        SSD_LAUNCH_CHECK();
+    }
     if (p.groups > 1 && !p.tickets && !(p.ablate & 24)) {
         const long nvec = (long)p.B * p.Ho * p.Wo * p.Cout / 4;
         const int blocks = (int)((nvec + 255) / 256 < 4096 ? (nvec + 255) / 256 : 4096);

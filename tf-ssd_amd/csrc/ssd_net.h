@@ -102,6 +102,7 @@ struct ssd_net {
     int tail_prio = 0;              // 1: extras tail on side[2] (highest priority); 2: its small heads too
     bool tail_on_side = false;      // diagnostics: big heads on the main stream, extras tail + small heads on the side streams
     bool image_split = true;        // fp32 nets: the finalize-time race also times the image kernel's split-bf16 form (img_choice 2; SSD_IMAGE_SPLIT=0 / option "image_split" 0: leave it out)
+    bool image_v2 = true;           // whole-image kernel: the second form (ssd_imgblock2.hip: compile-time geometry, adjacent pixels per lane) where it has a configuration; 0 = the first form (A/B, bitwise equal)
     bool conv_dma = true;           // offer the LDS-DMA tiles over pre-split activation planes (ssd_convdma.hip) to the autotune / accept them from tables
     bool image_ticket = false;      // combine the channel-group slabs inside the launch (arrival ticket) instead of by a second launch
     float* img_slabs = nullptr;     // its partial-sum slabs and arrival tickets (sized for max_batch)

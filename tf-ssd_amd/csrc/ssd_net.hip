@@ -383,6 +383,7 @@ static FusedBlockParams fused_params(const ssd_net& net, const Layer& f, int B) 
         // (the in-launch ticketed combine exists for the fp32-MFMA form only: a no-op for the bf16 / split-bf16 forms)
         p.tickets = net.image_ticket && !p.bf16 ? net.img_tickets : nullptr;
         if (!p.bf16 && f.img_choice == 2) { p.bf16 = 3; p.tickets = nullptr; }    // the split-bf16 form of the image kernel (fp32 results)
+        p.form2 = net.image_v2 ? 1 : 0;
     }
     return p;
 }
@@ -1613,6 +1614,11 @@ int ssd_net_set_option(ssd_net* net, const char* name, int value) {
     if (std::string(name) == "use_wino") {       // Winograd F(2x2,3x3) candidates in the autotune (default 1)
         net->use_wino = value != 0;
         net->finalized = false;
+        net->drop_graphs();
+        return SSD_OK;
+    }
+    if (std::string(name) == "image_v2") {       // whole-image kernel: second form (default 1) / first form (0); bitwise equal
+        net->image_v2 = value != 0;
         net->drop_graphs();
         return SSD_OK;
     }
