@@ -49,6 +49,9 @@ const Conv3Cfg kCfg3[] = {
     C3CFG(2, 4, 6, 2),    // 192 x 128, 12 waves
     C3CFG(3, 4, 4, 3),    // 192 x 192, 12 waves
     C3CFG(2, 4, 8, 2),    // 256 x 128, 16 waves (118 registers)
+    // round 6: the 150-column heads (A (L + 4) = 6 x 25) on ONE 160-wide tile column instead of two 128-wide ones (41 % of
+    // whose matrix work is padding), at 192 rows: head level 1 at B = 64 = 121 tiles x split-K 2 = 242 workgroups
+    C3CFG(2, 5, 6, 2),    // 192 x 160, 12 waves
 };
 constexpr int kNumCfg3 = sizeof(kCfg3) / sizeof(kCfg3[0]);
 int c3_lds_bytes(const Conv3Cfg& g, int planes) {

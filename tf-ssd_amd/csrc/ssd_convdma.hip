@@ -264,6 +264,7 @@ const ConvDCfg kCfgD[] = {
     DCFG(3, 4, 4, 3),    // 192 x 192, 12 waves
     DCFG(2, 4, 8, 2),    // 256 x 128, 16 waves
     DCFG(2, 2, 2, 2),    // 64 x 64, 4 waves
+    DCFG(2, 5, 6, 2),    // 192 x 160, 12 waves (round 6: the 150-column heads on one tile column)
 };
 constexpr int kNumCfgD = sizeof(kCfgD) / sizeof(kCfgD[0]);
 
