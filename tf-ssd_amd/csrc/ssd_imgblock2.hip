@@ -39,7 +39,11 @@ constexpr int kC = 16;            // expanded channels per chunk
 __device__ __forceinline__ void lds_barrier2() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 // (a __device__ body: a __global__ function that declares __amdgpu_buffer_rsrc_t objects loses its host stub)
-// LOOP 0: one chunk per iteration (runtime buffer parity, project every second chunk); 1: unrolled by chunk pairs
+// LOOP 0: one chunk per iteration (runtime buffer parity, project every second chunk); 1: unrolled by chunk pairs.
+// Measured and NOT kept (profiles/HISTORY.md, round 6): 12 waves x 2 pixels and 4 waves x 6 pixels (one wave per SIMD, 512
+// registers: 500+ v_accvgpr moves per pair), the pair loop with fenced phases + sched_group_barrier interleave, the two waves
+// of a SIMD walking an iteration in opposite order -- all equal or slower; the loop's time stays the SUM of its matrix, vector
+// and LDS time (phase ablation: tests/micro/imgblock2_prof.py on a -DSSD_IMAGE2_ABLATE build)
 template <int CIN, int NT, int NW, int T, int H, int W, int NP, int LOOP, int ABL>
 __device__ __forceinline__ void image16v2_body(const FusedBlockParams& p, float* __restrict__ sm2) {
     static_assert(CIN % 32 == 0, "whole 32-channel k-steps");
@@ -255,46 +259,21 @@ __device__ __forceinline__ void image16v2_body(const FusedBlockParams& p, float*
             if (c + 1 < nchunk) expand(c + 1, pb ^ 1);
         }
     } else {
-        // LOOP 2: the pair loop with the phases fenced and the matrix instructions of a phase interleaved with the vector work
-        // that does not depend on them (igrouplp: N x { 1 MFMA, D DS reads, V VALU })
-#define SSD_FENCE() do { if (LOOP == 2) __builtin_amdgcn_sched_barrier(0); } while (0)
-#define SSD_PIN(N, V, D)                                                        \
-    if (LOOP == 2) {                                                            \
-        _Pragma("unroll") for (int s_ = 0; s_ < (N); ++s_) {                    \
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                  \
-            if ((D) > 0) __builtin_amdgcn_sched_group_barrier(0x100, (D), 0);   \
-            if ((V) > 0) __builtin_amdgcn_sched_group_barrier(0x002, (V), 0);   \
-        }                                                                       \
-    }
-        constexpr int MFE = T * KS * (NP == 3 ? 6 : 1);        // matrix instructions of one expand
-        constexpr int MFP = T * NT * (NP == 3 ? 6 : 1);        // ... of one project (a chunk pair)
         for (int i = 0; i < nchunk; i += 2) {
             f32x4 a0[T], a1[T];
             dma_wait();
             lds_barrier2();          // E(i), We(i + 1) visible; everyone is done with E(i - 1) and with the pair before
             if (i + 2 < nchunk) dma_we(i + 2, 0);
             if (i > 0) dma_wp(i >> 1);
-            SSD_FENCE();
             depthwise(i, 0, a0);
             expand(i + 1, 1);
-            if (LOOP == 2) {         // the depthwise belongs to THIS phase (beside the expand's matrix instructions)
-#pragma unroll
-                for (int t = 0; t < T; ++t) asm volatile("" : "+v"(a0[t]));
-            }
-            SSD_PIN(MFE, 2, 1)
-            SSD_FENCE();
             dma_wait();
             lds_barrier2();          // E(i + 1), We(i + 2), Wp(pair) visible
             if (i + 3 < nchunk) dma_we(i + 3, 1);
-            SSD_FENCE();
             depthwise(i + 1, 1, a1);
             project(a0, a1);
-            SSD_PIN(MFP, 2, 1)
-            SSD_FENCE();
             if (i + 2 < nchunk) expand(i + 2, 0);
         }
-#undef SSD_PIN
-#undef SSD_FENCE
     }
 
     if (p.dbg) tk2 = (long long)__builtin_amdgcn_s_memtime();
@@ -351,28 +330,19 @@ struct Image2Cfg {
 #define I2ABL(A) {64, 4, 8, 3, 19, 19, mbv2_image16v2_kernel<64, 4, 8, 3, 19, 19, 1, 0, A>, mbv2_image16v2_kernel<64, 4, 8, 3, 19, 19, 3, 0, A>}
 const Image2Cfg kImage2[] = {       // (the first configuration of a shape is the default; SSD_IMAGE2_VARIANT=n picks the n-th: A/B runs)
     I2CFG(64, 4, 8, 3, 19, 19, 1),     // blocks 7-9:   64 -> 384 -> 64 at 19x19
-    I2CFG(64, 4, 8, 3, 19, 19, 2),
     I2CFG(64, 4, 8, 3, 19, 19, 0),
-    I2CFG(64, 4, 12, 2, 19, 19, 0),    //   ... three waves per SIMD, two pixels per lane
-    I2CFG(64, 4, 12, 2, 19, 19, 1),
-    I2CFG(64, 4, 4, 6, 19, 19, 0),     //   ... one wave per SIMD, six pixels per lane
-#ifdef SSD_IMAGE2_ABLATE               // diagnostics build: variants 5 .. 10 = the default with phases removed (wrong results)
+#ifdef SSD_IMAGE2_ABLATE               // diagnostics build: variants 2 .. 7 = the single-chunk loop with phases removed (wrong results)
     I2ABL(1), I2ABL(2), I2ABL(4), I2ABL(8), I2ABL(16), I2ABL(31),
 #endif
     I2CFG(64, 6, 8, 3, 19, 19, 1),     // block 10:     64 -> 384 -> 96
-    I2CFG(64, 6, 8, 3, 19, 19, 2),
     I2CFG(64, 6, 8, 3, 19, 19, 0),
-    I2CFG(64, 6, 12, 2, 19, 19, 0),
-    I2CFG(96, 6, 8, 3, 19, 19, 0),     // blocks 11-12: 96 -> 576 -> 96
-    I2CFG(96, 6, 8, 3, 19, 19, 1),
-    I2CFG(96, 6, 12, 2, 19, 19, 0),
+    I2CFG(96, 6, 8, 3, 19, 19, 0),     // blocks 11-12: 96 -> 576 -> 96 (the pair loop spills 84 registers here: 86 us against 52)
     I2CFG(160, 10, 8, 1, 10, 10, 1),   // blocks 14-15: 160 -> 960 -> 160 at 10x10
-    I2CFG(160, 10, 8, 1, 10, 10, 2),
     I2CFG(160, 10, 8, 1, 10, 10, 0),
     I2CFG(160, 20, 8, 1, 10, 10, 1),   // block 16:     160 -> 960 -> 320
-    I2CFG(160, 20, 8, 1, 10, 10, 2),
     I2CFG(160, 20, 8, 1, 10, 10, 0),
 };
+
 
 size_t image2_lds_bytes(const Image2Cfg& c, const FusedBlockParams& p, int G) {
     const int P = c.w + 1, npix = c.nw * 16 * c.t, NE = npix + 2 * P + 2, row = (c.t & 1) ? 24 : 20;
