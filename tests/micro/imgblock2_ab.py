@@ -20,7 +20,7 @@ if os.environ.get("SSD_AB_FORCE_SPLIT", "1") == "1" and prec == "fp32":
     t = "\n".join((l.rsplit(" ", 1)[0] + " 2") if " image " in l else l for l in m.get_tuning().splitlines()) + "\n"
     m.set_tuning(t)
 x = h.to_dev(data_utils.synthetic_images(B))
-names = ["block_%d_out" % k for k in range(7, 17)]
+names = ["block_%d_out" % k for k in range(7, 17)] + ["block_13_expand_relu"]
 res = {}
 for v in (0, 1):
     m.set_option("image_v2", v)

@@ -20,7 +20,8 @@
 //
 // The arithmetic (split, six-pack order, FMA order of the depthwise, chunk order of the project, slabs) is the first form's;
 // only the channel -> k-slot assignment inside a project MFMA differs (another order of the same 32-term fp32 sums).
-// Stride 1; a group takes whole chunk PAIRS (the Ce / 32 pairs dealt as evenly as they go over the groups: no lone last
+// Stride 1, and stride 2 for block 13 (one output pixel per lane, its expanded map -- SSD feature map 1 -- written to HBM from
+// the expand's epilogue); a group takes whole chunk PAIRS (the Ce / 32 pairs dealt as evenly as they go over the groups: no lone last
 // chunk); everything else keeps the first form.
 #include <cstdlib>
 
@@ -44,7 +45,7 @@ __device__ __forceinline__ void lds_barrier2() { asm volatile("s_waitcnt lgkmcnt
 // registers: 500+ v_accvgpr moves per pair), the pair loop with fenced phases + sched_group_barrier interleave, the two waves
 // of a SIMD walking an iteration in opposite order -- all equal or slower; the loop's time stays the SUM of its matrix, vector
 // and LDS time (phase ablation: tests/micro/imgblock2_prof.py on a -DSSD_IMAGE2_ABLATE build)
-template <int CIN, int NT, int NW, int T, int H, int W, int NP, int LOOP, int ABL>
+template <int CIN, int NT, int NW, int T, int H, int W, int NP, int LOOP, int ABL, int S = 1>
 __device__ __forceinline__ void image16v2_body(const FusedBlockParams& p, float* __restrict__ sm2) {
     static_assert(CIN % 32 == 0, "whole 32-channel k-steps");
     constexpr int NTH = NW * 64;
@@ -52,8 +53,13 @@ __device__ __forceinline__ void image16v2_body(const FusedBlockParams& p, float*
     static_assert(NW * 16 * T >= Q, "the waves' pixel slots cover the padded map");
     constexpr int NPIX = NW * 16 * T;
     constexpr int NE = NPIX + 2 * P + 2;           // E rows: index q + P + 1, zero rows above / below
-    constexpr int ROW = (T & 1) ? 24 : 20;         // floats per E row (16 used)
-    static_assert((T * ROW) % 16 == 8, "lanes T pixels apart must sit 8 (mod 16) words apart");
+    // floats per E row (16 used).  Stride 1: the window reads of lanes T pixels apart; stride 2 (block 13): the window reads of
+    // lanes TWO pixels apart (one output pixel per lane) -- both want 8 (mod 16) words between neighbouring lanes
+    constexpr int ROW = S == 2 ? 20 : (T & 1) ? 24 : 20;
+    static_assert(((S == 2 ? 2 : T) * ROW) % 16 == 8, "neighbouring lanes must sit 8 (mod 16) words apart");
+    constexpr int TO = S == 1 ? T : 1;             // output pixels per lane
+    constexpr int Ho = S == 1 ? H : (H + 1) / 2, Wo = S == 1 ? W : (W + 1) / 2, Po = Wo + 1;
+    static_assert(S == 1 || NW * 16 >= Ho * Po, "stride 2: one output pixel per lane covers the output map");
     constexpr int WPL = NP == 1 ? 3 : 0;           // first plane read of [h, m, l, r]
     constexpr int KS = CIN / 32;                   // k-steps of the expand
     constexpr int EBUF = NE * ROW;                 // floats per E buffer
@@ -150,7 +156,7 @@ __device__ __forceinline__ void image16v2_body(const FusedBlockParams& p, float*
 
     // one address register each: the lane's E row of pixel q0 (+ the buffer / tap / pixel offsets as immediates), its
     // parameter vector, its fragment slot inside a 1 KB weight block
-    const float* e_rd = Es + (q0 + P + 1) * ROW + g4 * 4;
+    const float* e_rd = Es + (q0 + P + 1) * ROW + g4 * 4;       // (stride 2: re-pointed at the lane's output pixel below)
     float* e_wr = Es + (q0 + P + 1) * ROW + g4 * 4;
     const float* ps_l = Ps + g4 * 4;
     const int fslot = l15 * 32 + ((g4 ^ ((l15 >> 1) & 3)) * 8);
@@ -159,6 +165,20 @@ __device__ __forceinline__ void image16v2_body(const FusedBlockParams& p, float*
     float relu_hi[T];
 #pragma unroll
     for (int t = 0; t < T; ++t) relu_hi[t] = real[t] ? 6.0f : 0.0f;       // relu6 at real pixels, 0 at pad positions
+    // output side: the same pixels for stride 1; stride 2: ONE pixel of the Ho x Wo map per lane (own pixel line qo = ro *
+    // (Wo + 1) + co), its 3 x 3 window centred at (2 ro - pad_t + 1, 2 co - pad_l + 1) of the E map (TF SAME pads)
+    bool realo[TO];
+    int opo[TO];
+    if constexpr (S == 1) {
+#pragma unroll
+        for (int t = 0; t < T; ++t) { realo[t] = real[t]; opo[t] = opix[t]; }
+    } else {
+        const int qo = wave * 16 + l15, ro = qo / Po, co = qo - ro * Po;
+        const bool in = qo < Ho * Po;
+        realo[0] = in && co < Wo;
+        opo[0] = realo[0] ? ro * Wo + co : 0;
+        e_rd = Es + ((in ? (2 * ro - p.pad_t + 1) * P + (2 * co - p.pad_l + 1) : 0) + P + 1) * ROW + g4 * 4;
+    }
 
     // expand chunk j into E buffer pb: E = relu6(We x X + shift)
     auto expand = [&](const int j, const int pb) {
@@ -182,48 +202,54 @@ __device__ __forceinline__ void image16v2_body(const FusedBlockParams& p, float*
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] = __builtin_amdgcn_fmed3f(v[e], 0.0f, relu_hi[t]);
             *reinterpret_cast<f32x4*>(ew + t * ROW) = v;
+            if (S == 2 && p.e_out && real[t]) {       // block 13: the expanded map is SSD feature map 1 -- written once, from here
+                const int ch = cbeg + (j >> 1) * 32 + g4 * 8 + (j & 1) * 4;       // the lane's four channels of chunk j
+                *reinterpret_cast<f32x4*>(p.e_out + ((long)img * (H * W) + opix[t]) * p.Ce + ch) = v;
+                if (p.e_planes) store_planes4(p.e_planes, p.e_plane, p.planes_np, (long)img * (H * W) + opix[t], ch, (long)B * (H * W), v);
+            }
         }
     };
-    // depthwise of chunk i from E buffer pb: the lane's T pixels x 4 channels = the project MFMA's B fragment
-    auto depthwise = [&](const int i, const int pb, f32x4 (&a)[T]) {
+    // depthwise of chunk i from E buffer pb: the lane's TO output pixels x 4 channels = the project MFMA's B fragment
+    auto depthwise = [&](const int i, const int pb, f32x4 (&a)[TO]) {
         const float* pc = ps_l + i * PCH;
         const f32x4 dh = *reinterpret_cast<const f32x4*>(pc + 10 * kC);
 #pragma unroll
-        for (int t = 0; t < T; ++t) a[t] = dh;
+        for (int t = 0; t < TO; ++t) a[t] = dh;
         const float* es = e_rd + pb * EBUF;
 #pragma unroll
         for (int dy = -1; dy <= 1; ++dy) {
-            f32x4 w[3], e[T + 2];
+            f32x4 w[3], e[TO + 2];
 #pragma unroll
             for (int dx = 0; dx < 3; ++dx) w[dx] = *reinterpret_cast<const f32x4*>(pc + (1 + (dy + 1) * 3 + dx) * kC);
 #pragma unroll
-            for (int j = 0; j < T + 2; ++j) e[j] = (ABL & 16) ? w[j % 3] : *reinterpret_cast<const f32x4*>(es + (dy * P + j - 1) * ROW);
+            for (int j = 0; j < TO + 2; ++j)
+                e[j] = (ABL & 16) ? w[j % 3] : *reinterpret_cast<const f32x4*>(es + (dy * P + j - 1) * ROW);
 #pragma unroll
             for (int dx = 0; dx < 3; ++dx)
 #pragma unroll
-                for (int t = 0; t < T; ++t) {
+                for (int t = 0; t < TO; ++t) {
                     if (ABL & 2) a[t] += e[t + dx];
                     else a[t] += e[t + dx] * w[dx];
                 }
         }
 #pragma unroll
-        for (int t = 0; t < T; ++t)
+        for (int t = 0; t < TO; ++t)
 #pragma unroll
             for (int e = 0; e < 4; ++e) a[t][e] = __builtin_amdgcn_fmed3f(a[t][e], 0.0f, 6.0f);
     };
-    f32x4 acc[T][NT];
+    f32x4 acc[TO][NT];
 #pragma unroll
-    for (int t = 0; t < T; ++t)
+    for (int t = 0; t < TO; ++t)
 #pragma unroll
         for (int ni = 0; ni < NT; ++ni) acc[t][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
     // project of a chunk pair: K = 32 = the lane's 4 + 4 channels of the two chunks (k-slots g4 * 8 ..)
-    auto project = [&](const f32x4 (&a0)[T], const f32x4 (&a1)[T]) {
-        BP<NP> d[T];
+    auto project = [&](const f32x4 (&a0)[TO], const f32x4 (&a1)[TO]) {
+        BP<NP> d[TO];
 #pragma unroll
-        for (int t = 0; t < T; ++t) d[t] = (ABL & 8) ? xs[t][0] : splitN<NP>(a0[t], a1[t]);
+        for (int t = 0; t < TO; ++t) d[t] = (ABL & 8) ? xs[t][0] : splitN<NP>(a0[t], a1[t]);
         if (ABL & 8) {
 #pragma unroll
-            for (int t = 0; t < T; ++t) asm volatile("" :: "v"(a0[t]), "v"(a1[t]));
+            for (int t = 0; t < TO; ++t) asm volatile("" :: "v"(a0[t]), "v"(a1[t]));
         }
 #pragma unroll
         for (int ni = 0; ni < NT; ++ni) {
@@ -231,7 +257,7 @@ __device__ __forceinline__ void image16v2_body(const FusedBlockParams& p, float*
 #pragma unroll
             for (int pl = 0; pl < NP; ++pl) wa.p[pl] = *reinterpret_cast<const bf16x8*>(wp_l + (pl * NT + ni) * 512);
 #pragma unroll
-            for (int t = 0; t < T; ++t) {
+            for (int t = 0; t < TO; ++t) {
                 if (!(ABL & 4)) acc[t][ni] = mmaN<NP>(wa, d[t], acc[t][ni]);
                 else asm volatile("" :: "v"(d[t].p[0]), "v"(wa.p[0]));
             }
@@ -241,18 +267,18 @@ __device__ __forceinline__ void image16v2_body(const FusedBlockParams& p, float*
     expand(0, 0);
 
     if constexpr (LOOP == 0) {
-        f32x4 dprev[T];
+        f32x4 dprev[TO];
         for (int c = 0; c < nchunk; ++c) {
             dma_wait();              // the copies issued an iteration ago have landed ...
             lds_barrier2();          // ... and are visible; E(c) is visible; everyone is done with E(c - 1)
             const int pb = c & 1;
             if (c + 2 < nchunk) dma_we(c + 2, pb);                  // the stage expand(c) read before this barrier
             if (!pb && c > 0) dma_wp(c >> 1);                       // everyone projected the pair before at iteration c - 1
-            f32x4 a[T];
+            f32x4 a[TO];
             depthwise(c, pb, a);
             if (!pb) {
 #pragma unroll
-                for (int t = 0; t < T; ++t) dprev[t] = a[t];
+                for (int t = 0; t < TO; ++t) dprev[t] = a[t];
             } else {
                 project(dprev, a);
             }
@@ -260,7 +286,7 @@ __device__ __forceinline__ void image16v2_body(const FusedBlockParams& p, float*
         }
     } else {
         for (int i = 0; i < nchunk; i += 2) {
-            f32x4 a0[T], a1[T];
+            f32x4 a0[TO], a1[TO];
             dma_wait();
             lds_barrier2();          // E(i), We(i + 1) visible; everyone is done with E(i - 1) and with the pair before
             if (i + 2 < nchunk) dma_we(i + 2, 0);
@@ -286,48 +312,49 @@ __device__ __forceinline__ void image16v2_body(const FusedBlockParams& p, float*
         }
     };
     // ---- epilogue (fp32): G = 1 direct; G > 1 partial-sum slab, combined by image_combine_kernel
-    const long img_off = (long)img * (H * W) * p.Cout;
+    const long img_off = (long)img * (Ho * Wo) * p.Cout;
     if (G == 1) {
 #pragma unroll
-        for (int t = 0; t < T; ++t) {
-            if (!real[t]) continue;
-            float* yp = p.y + img_off + (long)opix[t] * p.Cout + g4 * 4;
+        for (int t = 0; t < TO; ++t) {
+            if (!realo[t]) continue;
+            float* yp = p.y + img_off + (long)opo[t] * p.Cout + g4 * 4;
 #pragma unroll
             for (int ni = 0; ni < NT; ++ni) {
                 f32x4 v = acc[t][ni] + *reinterpret_cast<const f32x4*>(p.ph + ni * 16 + g4 * 4);
-                if (p.residual)
-                    v = v + *reinterpret_cast<const f32x4*>(p.x + img_off + (long)opix[t] * p.Cout + ni * 16 + g4 * 4);
+                if (S == 1 && p.residual)
+                    v = v + *reinterpret_cast<const f32x4*>(p.x + img_off + (long)opo[t] * p.Cout + ni * 16 + g4 * 4);
                 *reinterpret_cast<f32x4*>(yp + ni * 16) = v;
-                if (p.y_planes) store_planes4(p.y_planes, p.y_plane, p.planes_np, (long)img * (H * W) + opix[t], g4 * 4 + ni * 16, (long)B * (H * W), v);
+                if (p.y_planes) store_planes4(p.y_planes, p.y_plane, p.planes_np, (long)img * (Ho * Wo) + opo[t], g4 * 4 + ni * 16, (long)B * (Ho * Wo), v);
             }
         }
         dump();
         return;
     }
-    const long slab_stride = (long)B * (H * W) * p.Cout;
+    const long slab_stride = (long)B * (Ho * Wo) * p.Cout;
     float* sp = p.slabs + (long)grp * slab_stride + img_off + g4 * 4;
 #pragma unroll
-    for (int t = 0; t < T; ++t) {
-        if (!real[t]) continue;
+    for (int t = 0; t < TO; ++t) {
+        if (!realo[t]) continue;
 #pragma unroll
-        for (int ni = 0; ni < NT; ++ni) *reinterpret_cast<f32x4*>(sp + (long)opix[t] * p.Cout + ni * 16) = acc[t][ni];
+        for (int ni = 0; ni < NT; ++ni) *reinterpret_cast<f32x4*>(sp + (long)opo[t] * p.Cout + ni * 16) = acc[t][ni];
     }
     dump();
 }
 
-template <int CIN, int NT, int NW, int T, int H, int W, int NP, int LOOP, int ABL = 0>
+template <int CIN, int NT, int NW, int T, int H, int W, int NP, int LOOP, int ABL = 0, int S = 1>
 __global__ __launch_bounds__(NW * 64) void mbv2_image16v2_kernel(const FusedBlockParams p) {
     extern __shared__ __attribute__((aligned(1024))) float sm2[];
-    image16v2_body<CIN, NT, NW, T, H, W, NP, LOOP, ABL>(p, sm2);
+    image16v2_body<CIN, NT, NW, T, H, W, NP, LOOP, ABL, S>(p, sm2);
 }
 
 typedef void (*image2_kernel_t)(const FusedBlockParams);
 struct Image2Cfg {
-    int cin, nt, nw, t, h, w;
+    int cin, nt, nw, t, h, w, stride;
     image2_kernel_t fn1, fn3;       // bf16 mode (NP = 1), split-bf16 form (NP = 3)
 };
-#define I2CFG(CIN, NT, NW, T, H, W, LOOP) {CIN, NT, NW, T, H, W, mbv2_image16v2_kernel<CIN, NT, NW, T, H, W, 1, LOOP>, mbv2_image16v2_kernel<CIN, NT, NW, T, H, W, 3, LOOP>}
-#define I2ABL(A) {64, 4, 8, 3, 19, 19, mbv2_image16v2_kernel<64, 4, 8, 3, 19, 19, 1, 0, A>, mbv2_image16v2_kernel<64, 4, 8, 3, 19, 19, 3, 0, A>}
+#define I2CFG(CIN, NT, NW, T, H, W, LOOP) {CIN, NT, NW, T, H, W, 1, mbv2_image16v2_kernel<CIN, NT, NW, T, H, W, 1, LOOP>, mbv2_image16v2_kernel<CIN, NT, NW, T, H, W, 3, LOOP>}
+#define I2ABL(A) {64, 4, 8, 3, 19, 19, 1, mbv2_image16v2_kernel<64, 4, 8, 3, 19, 19, 1, 0, A>, mbv2_image16v2_kernel<64, 4, 8, 3, 19, 19, 3, 0, A>}
+#define I2CFG2(CIN, NT, NW, T, H, W, LOOP) {CIN, NT, NW, T, H, W, 2, mbv2_image16v2_kernel<CIN, NT, NW, T, H, W, 1, LOOP, 0, 2>, mbv2_image16v2_kernel<CIN, NT, NW, T, H, W, 3, LOOP, 0, 2>}
 const Image2Cfg kImage2[] = {       // (the first configuration of a shape is the default; SSD_IMAGE2_VARIANT=n picks the n-th: A/B runs)
     I2CFG(64, 4, 8, 3, 19, 19, 1),     // blocks 7-9:   64 -> 384 -> 64 at 19x19
     I2CFG(64, 4, 8, 3, 19, 19, 0),
@@ -337,6 +364,8 @@ const Image2Cfg kImage2[] = {       // (the first configuration of a shape is th
     I2CFG(64, 6, 8, 3, 19, 19, 1),     // block 10:     64 -> 384 -> 96
     I2CFG(64, 6, 8, 3, 19, 19, 0),
     I2CFG(96, 6, 8, 3, 19, 19, 0),     // blocks 11-12: 96 -> 576 -> 96 (the pair loop spills 84 registers here: 86 us against 52)
+    I2CFG2(96, 10, 8, 3, 19, 19, 0),   // block 13:     96 -> 576 -> 160, depthwise stride 2 (19x19 -> 10x10), E written out
+    I2CFG2(96, 10, 8, 3, 19, 19, 1),
     I2CFG(160, 10, 8, 1, 10, 10, 1),   // blocks 14-15: 160 -> 960 -> 160 at 10x10
     I2CFG(160, 10, 8, 1, 10, 10, 0),
     I2CFG(160, 20, 8, 1, 10, 10, 1),   // block 16:     160 -> 960 -> 320
@@ -345,7 +374,7 @@ const Image2Cfg kImage2[] = {       // (the first configuration of a shape is th
 
 
 size_t image2_lds_bytes(const Image2Cfg& c, const FusedBlockParams& p, int G) {
-    const int P = c.w + 1, npix = c.nw * 16 * c.t, NE = npix + 2 * P + 2, row = (c.t & 1) ? 24 : 20;
+    const int P = c.w + 1, npix = c.nw * 16 * c.t, NE = npix + 2 * P + 2, row = c.stride == 2 ? 20 : (c.t & 1) ? 24 : 20;
     const int np = p.bf16 == 3 ? 3 : 1, ks = c.cin / 32;
     const size_t w = (size_t)(2 * np * ks + np * c.nt) * 1024;      // Wes (two stages) + Wps
     const int pairs = p.Ce / (2 * kC), cmax = ((pairs + G - 1) / G) * 2 * kC;      // channels of the largest group
@@ -353,11 +382,14 @@ size_t image2_lds_bytes(const Image2Cfg& c, const FusedBlockParams& p, int G) {
 }
 
 const Image2Cfg* pick_image2(const FusedBlockParams& p, int variant) {
-    if (!p.bf16 || p.stride != 1 || p.e_out || p.H != p.Ho || p.W != p.Wo || p.Ce % (2 * kC) != 0 || p.kpad_e % 32 != 0 || p.kpad_p % 32 != 0) return nullptr;
+    if (!p.bf16 || p.Ce % (2 * kC) != 0 || p.kpad_e % 32 != 0 || p.kpad_p % 32 != 0) return nullptr;
+    if (p.stride == 1 && (p.e_out || p.H != p.Ho || p.W != p.Wo)) return nullptr;
+    if (p.stride == 2 && (p.residual || p.Ho != (p.H + 1) / 2 || p.Wo != (p.W + 1) / 2 || p.pad_t < 0 || p.pad_t > 1 || p.pad_l < 0 || p.pad_l > 1)) return nullptr;
+    if (p.stride != 1 && p.stride != 2) return nullptr;
     if (p.residual && p.Cin != p.Cout) return nullptr;
     int seen = 0;
     for (const auto& c : kImage2)
-        if (c.cin == p.Cin && c.nt * 16 == p.Cout && c.h == p.H && c.w == p.W && p.kpad_e == c.cin && p.npad_p >= c.nt * 16 && seen++ == variant) return &c;
+        if (c.cin == p.Cin && c.nt * 16 == p.Cout && c.h == p.H && c.w == p.W && c.stride == p.stride && p.kpad_e == c.cin && p.npad_p >= c.nt * 16 && seen++ == variant) return &c;
     return nullptr;
 }
 
