@@ -734,6 +734,34 @@ def test_image_block_kernel_vs_layer_kernels(B, ticket):
         np.testing.assert_array_equal(m.fetch_activation(n), got[n])
 
 
+@pytest.mark.parametrize("B,S", [(5, 300), (64, 300), (3, 512)])
+def test_band3_weights_through_lds_dma_bitwise(B, S):
+    """The split row-band kernel (blocks 3-6) with its weight fragments staged by LDS-DMA (two We stages + one Wp stage of 1 KB
+    blocks; option image_v2 = the "second forms", default) against the form that prefetches them into registers: the SAME
+    arithmetic in the same order -- block 6's output (stem + blocks 1-6) is bitwise equal, incl. the lone last chunk of the
+    144-channel block 3 and the 512 x 512 graph's pitches."""
+    from models.ssd_mobilenet_v2 import get_model
+    hp = helpers.hyper_params("mobilenet_v2")
+    if S == 512:
+        hp["img_size"] = 512
+        hp["feature_map_shapes"] = [32, 16, 8, 4, 2, 1]
+    w = helpers.synthetic_weights("mobilenet_v2", hp)
+    x = helpers.images(min(B, 8), S, seed=23)
+    if B > 8:
+        x = np.concatenate([x] * ((B + 7) // 8))[:B] * np.linspace(0.5, 1.0, B, dtype=np.float32)[:, None, None, None]
+    m = get_model(hp, max_batch=B)
+    m.set_weights(w)
+    got = {}
+    for v in (0, 1):
+        m.set_option("image_v2", v)
+        m(x)
+        assert any(l["name"] == "block_4_fused" and l["config"] == "band3" and l["flops"] > 0 for l in m.layers(B))
+        got[v] = {n: m.fetch_activation(n).copy() for n in ("block_3_out", "block_5_out", "block_6_out")}
+    for n in got[0]:
+        np.testing.assert_array_equal(got[0][n].view(np.uint32), got[1][n].view(np.uint32))
+    assert np.abs(got[1]["block_6_out"]).max() > 0
+
+
 @pytest.mark.parametrize("B,second", [(3, 1), (3, 0), (24, 1), (64, 1), (64, 0), (232, 1)])
 def test_image_block_split_form_vs_layer_kernels(B, second):
     """(``second`` = option image_v2: the kernel's second form, csrc/ssd_imgblock2.hip -- compile-time geometry, adjacent

@@ -63,14 +63,17 @@ __global__ __launch_bounds__(256) void split3_wp_kernel(const float* __restrict_
 // NP = 3: fp32 results through the exact three-way split (six MFMAs per product); NP = 1: the net's bf16 mode (operands
 // rounded once, one MFMA per product, plane 3 of the packed weights) -- a third of the plane registers, so blocks 1-2
 // (T = 9 / 8 tiles per wave) fit as well
-template <int CIN, int NT, int T, int TO, int S, int P, int NP>
-__global__ __launch_bounds__(kB3Threads) void mbv2_band3_block_kernel(const FusedBlockParams p) {
+// WDMA (round 6, the whole-image kernel's recipe): the weight fragments reach LDS by LDS-DMA (two We stages, one Wp stage; 1 KB
+// blocks of 16 rows x 32 bf16, quad-swizzled through the per-lane source offset) instead of waiting in registers one chunk ahead:
+// 36 - 60 registers less, no per-chunk 64-bit addresses
+typedef __attribute__((address_space(3))) void* b3_lds_dst_t;
+template <int CIN, int NT, int T, int TO, int S, int P, int NP, bool WDMA>
+__device__ __forceinline__ void band3_body(const FusedBlockParams& p, char* __restrict__ smem) {
     constexpr int WPL = NP == 1 ? 3 : 0;
     static_assert(P % 8 == 0 && CIN <= 32 && CIN % 8 == 0, "");
     constexpr int NE = b3_ne(T);
     constexpr int EBUF = NE * kB3C * 4;
 
-    extern __shared__ __attribute__((aligned(16))) char smem[];
     char* Es = smem;
     float* Ps = reinterpret_cast<float*>(smem + 2 * EBUF);       // [11][Ce]
 
@@ -134,21 +137,57 @@ __global__ __launch_bounds__(kB3Threads) void mbv2_band3_block_kernel(const Fuse
         }
     }
 
+    short* Wes = reinterpret_cast<short*>(Ps + 11 * Ce);         // WDMA: [2][NP] blocks of 512 bf16
+    short* Wps = Wes + 2 * NP * 512;                             //       [NP][NT] blocks
+    const int fslot = l15 * 32 + ((g4 ^ ((l15 >> 1) & 3)) * 8);  // the lane's fragment slot inside a block
+    const int dr = lane >> 2, dq8 = ((lane & 3) ^ ((lane >> 3) & 3)) * 8;
+    const __amdgpu_buffer_rsrc_t rs_e = __builtin_amdgcn_make_buffer_rsrc(const_cast<short*>(p.we3 + WPL * plane_e), 0, (int)(NP * plane_e * 2), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_p = __builtin_amdgcn_make_buffer_rsrc(const_cast<short*>(p.wp3 + WPL * plane_p), 0, (int)(NP * plane_p * 2), 0x00020000);
+    const int voff_e = (dr * 32 + dq8) * 2, voff_p = (dr * npairs * 32 + dq8) * 2;
+    auto dma_we = [&](int j, int stage) {
+        for (int b = wave; b < NP; b += 8)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_e, (b3_lds_dst_t)(Wes + (stage * NP + b) * 512), 16, voff_e,
+                                                     (int)((b * plane_e + (long)j * kB3C * 32) * 2), 0, 0);
+    };
+    auto dma_wp = [&](int pair) {
+        for (int b = wave; b < NP * NT; b += 8) {
+            const int pl = b / NT, ni = b - pl * NT;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_p, (b3_lds_dst_t)(Wps + b * 512), 16, voff_p,
+                                                     (int)((pl * plane_p + ((long)ni * 16 * npairs + pair) * 32) * 2), 0, 0);
+        }
+    };
+    auto dma_wait = [&]() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); };
     auto load_we = [&](int j) {
         BP<NP> w;
-        const short* base = p.we3 + WPL * plane_e + ((long)(j * kB3C + l15) * 32 + g4 * 8);
+        if constexpr (WDMA) {
 #pragma unroll
-        for (int pl = 0; pl < NP; ++pl) w.p[pl] = *reinterpret_cast<const bf16x8*>(base + pl * plane_e);
+            for (int pl = 0; pl < NP; ++pl) w.p[pl] = *reinterpret_cast<const bf16x8*>(Wes + ((j & 1) * NP + pl) * 512 + fslot);
+        } else {
+            const short* base = p.we3 + WPL * plane_e + ((long)(j * kB3C + l15) * 32 + g4 * 8);
+#pragma unroll
+            for (int pl = 0; pl < NP; ++pl) w.p[pl] = *reinterpret_cast<const bf16x8*>(base + pl * plane_e);
+        }
         return w;
     };
     auto load_wp = [&](BP<NP> (&w)[NT], int pair) {
 #pragma unroll
         for (int ni = 0; ni < NT; ++ni) {
-            const short* base = p.wp3 + WPL * plane_p + ((((long)(ni * 16 + l15) * npairs + pair) * 4 + g4) * 8);
+            if constexpr (WDMA) {
 #pragma unroll
-            for (int pl = 0; pl < NP; ++pl) w[ni].p[pl] = *reinterpret_cast<const bf16x8*>(base + pl * plane_p);
+                for (int pl = 0; pl < NP; ++pl) w[ni].p[pl] = *reinterpret_cast<const bf16x8*>(Wps + (pl * NT + ni) * 512 + fslot);
+            } else {
+                const short* base = p.wp3 + WPL * plane_p + ((((long)(ni * 16 + l15) * npairs + pair) * 4 + g4) * 8);
+#pragma unroll
+                for (int pl = 0; pl < NP; ++pl) w[ni].p[pl] = *reinterpret_cast<const bf16x8*>(base + pl * plane_p);
+            }
         }
     };
+    if constexpr (WDMA) {
+        dma_we(0, 0);
+        if (nchunk > 1) dma_we(1, 1);
+        dma_wp(0);
+        dma_wait();
+    }
     __syncthreads();
 
     auto expand = [&](int j, const BP<NP>& wa) {
@@ -182,6 +221,51 @@ __global__ __launch_bounds__(kB3Threads) void mbv2_band3_block_kernel(const Fuse
         for (int ni = 0; ni < NT; ++ni) acc[t][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
 
+    if constexpr (WDMA) {
+        expand(0, load_we(0));
+        for (int i = 0; i < nchunk; ++i) {
+            dma_wait();                 // the copies of an iteration ago have landed ...
+            b3_lds_barrier();           // ... and are visible; E(i) is complete; everyone is done reading E(i - 1)
+            const bool odd = i & 1, last = i + 1 == nchunk;
+            const bool flush = odd || last;
+            if (i + 2 < nchunk) dma_we(i + 2, i & 1);           // the stage expand(i) read before this barrier
+            if (!odd && i > 0) dma_wp(i >> 1);                  // everyone projected the pair before at iteration i - 1
+            if (!odd && last && i > 0) {                        // a lone last chunk projects in the iteration its weights are issued in
+                dma_wait();
+                b3_lds_barrier();
+            }
+            const char* eb = Es + (i & 1) * EBUF;
+            f32x4 w[9];
+#pragma unroll
+            for (int k = 0; k < 9; ++k) w[k] = *reinterpret_cast<const f32x4*>(Ps + (1 + k) * Ce + i * kB3C + g4 * 4);
+            const f32x4 dh = *reinterpret_cast<const f32x4*>(Ps + 10 * Ce + i * kB3C + g4 * 4);
+#pragma unroll
+            for (int t = 0; t < TO; ++t) {
+                if (t >= nto) break;
+                f32x4 d = dh;
+#pragma unroll
+                for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+                    for (int dx = 0; dx < 3; ++dx)
+                        d += *reinterpret_cast<const f32x4*>(eb + ea[t][dx] + dy * P * 64) * w[dy * 3 + dx];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) d[e] = __builtin_amdgcn_fmed3f(d[e], 0.0f, 6.0f);
+                if (!flush) {
+                    dprev[t] = d;
+                } else {
+                    const BP<NP> ds = odd ? splitN<NP>(dprev[t], d) : splitN<NP>(d, f32x4{0.f, 0.f, 0.f, 0.f});
+#pragma unroll
+                    for (int ni = 0; ni < NT; ++ni) {
+                        BP<NP> wpf;
+#pragma unroll
+                        for (int pl = 0; pl < NP; ++pl) wpf.p[pl] = *reinterpret_cast<const bf16x8*>(Wps + (pl * NT + ni) * 512 + fslot);
+                        acc[t][ni] = mmaN<NP>(wpf, ds, acc[t][ni]);
+                    }
+                }
+            }
+            if (i + 1 < nchunk) expand(i + 1, load_we(i + 1));
+        }
+    } else {
     BP<NP> wa = load_we(0);
     expand(0, wa);
     if (nchunk > 1) wa = load_we(1);
@@ -220,6 +304,7 @@ __global__ __launch_bounds__(kB3Threads) void mbv2_band3_block_kernel(const Fuse
             if (i + 2 < nchunk) wa = load_we(i + 2);        // in flight across the barrier and the next depthwise
         }
     }
+    }
 
     const long img_o = (long)img * Ho * Wo;
 #pragma unroll
@@ -236,20 +321,34 @@ __global__ __launch_bounds__(kB3Threads) void mbv2_band3_block_kernel(const Fuse
     }
 }
 
+template <int CIN, int NT, int T, int TO, int S, int P, int NP, bool WDMA = false>
+__global__ __launch_bounds__(kB3Threads) void mbv2_band3_block_kernel(const FusedBlockParams p) {
+    extern __shared__ __attribute__((aligned(1024))) char smem_b3[];
+    band3_body<CIN, NT, T, TO, S, P, NP, WDMA>(p, smem_b3);
+}
+
 typedef void (*band3_kernel_t)(const FusedBlockParams);
 struct Band3Cfg {
     int cin, nt, t, to, stride, pitch;
     band3_kernel_t fn;          // split-bf16 (fp32 results); nullptr: the shape only exists in the bf16 form
     band3_kernel_t fn1;         // bf16 (precision 1)
+    band3_kernel_t fn_d, fn1_d; // the same with the weights staged by LDS-DMA (FusedBlockParams.form2)
 };
-#define B3CFG(CIN, NT, T, TO, S, P) {CIN, NT, T, TO, S, P, mbv2_band3_block_kernel<CIN, NT, T, TO, S, P, 3>, mbv2_band3_block_kernel<CIN, NT, T, TO, S, P, 1>}
-#define B1CFG(CIN, NT, T, TO, S, P) {CIN, NT, T, TO, S, P, nullptr, mbv2_band3_block_kernel<CIN, NT, T, TO, S, P, 1>}
+#define B3CFG(CIN, NT, T, TO, S, P) {CIN, NT, T, TO, S, P, mbv2_band3_block_kernel<CIN, NT, T, TO, S, P, 3>, mbv2_band3_block_kernel<CIN, NT, T, TO, S, P, 1>, \
+                                     mbv2_band3_block_kernel<CIN, NT, T, TO, S, P, 3, true>, mbv2_band3_block_kernel<CIN, NT, T, TO, S, P, 1, true>}
+#define B3DCFG(CIN, NT, T, TO, S, P) {CIN, NT, T, TO, S, P, nullptr, nullptr, mbv2_band3_block_kernel<CIN, NT, T, TO, S, P, 3, true>, nullptr}
+#define B1CFG(CIN, NT, T, TO, S, P) {CIN, NT, T, TO, S, P, nullptr, mbv2_band3_block_kernel<CIN, NT, T, TO, S, P, 1>, nullptr, mbv2_band3_block_kernel<CIN, NT, T, TO, S, P, 1, true>}
 const Band3Cfg kBand3[] = {
     B1CFG(16, 2, 9, 2, 2, 152),   // bf16 form only: block 1 (16 -> 96 -> 24, 150x150 -> 75x75) and block 2 (75x75), the
     B1CFG(24, 2, 8, 6, 1, 80),    // fp32 band kernel's shapes
     B1CFG(24, 2, 8, 6, 1, 136),   // block 2 of the 512x512 graph
     // blocks 1-2 (Cin 16 / 24, T = 9 / 6 tiles per wave) stay on the fp32 band kernel: the three split X planes cost
     // 12 registers per tile, the kernel spilled (9 / 46 registers) and measured 149-158 / 162-172 us against 143 / 105
+    // round 6: with the weight fragments in LDS the split form of blocks 1-2 fits (second form only; block 1 with 8 tile slots per
+    // wave = 2 output rows per band, so that E + the weight stages stay below 160 KB)
+    B3DCFG(16, 2, 8, 2, 2, 152),
+    B3DCFG(24, 2, 7, 5, 1, 80),
+    B3DCFG(24, 2, 6, 4, 1, 80),
     B3CFG(24, 2, 7, 2, 2, 80),    // block 3
     B3CFG(32, 2, 4, 4, 1, 40),    // blocks 4-5
     B3CFG(32, 4, 4, 1, 2, 40),    // block 6
@@ -266,7 +365,9 @@ int band3_max_rows(const Band3Cfg& c, const FusedBlockParams& p) {
     return r;
 }
 
+size_t band3_lds_bytes(const Band3Cfg& c, const FusedBlockParams& p);
 const Band3Cfg* pick_band3(const FusedBlockParams& p, bool bf16) {
+    static const int split12 = getenv("SSD_BAND3_SPLIT12") ? atoi(getenv("SSD_BAND3_SPLIT12")) : 0;   // blocks 1-2 on the split form (experiment; 2: block 2's smaller band)
     if (p.Ce % kB3C != 0 || p.Cout % 8 != 0 || p.Cin > 32) return nullptr;
     if (p.stride == 1 && (p.H != p.Ho || p.W != p.Wo || p.pad_t != 1 || p.pad_l != 1)) return nullptr;
     if (p.stride == 2 && (p.residual || p.Ho != (p.H + 1) / 2 || p.Wo != (p.W + 1) / 2 || p.pad_t > 1 || p.pad_l > 1 ||
@@ -276,7 +377,9 @@ const Band3Cfg* pick_band3(const FusedBlockParams& p, bool bf16) {
     if (p.e_out) return nullptr;
     for (const auto& c : kBand3) {
         if (c.cin != p.Cin || c.stride != p.stride || (p.Cout + 15) / 16 != c.nt || p.npad_p < c.nt * 16) continue;
-        if (!bf16 && !c.fn) continue;
+        if (bf16 ? !c.fn1 : !(c.fn || (split12 && p.form2 && c.fn_d))) continue;
+        if (!bf16 && !c.fn && split12 == 2 && c.cin == 24 && c.t == 7) continue;
+        if (!bf16 && !c.fn && band3_lds_bytes(c, p) + (size_t)3 * (2 + c.nt) * 1024 > 160 * 1024) continue;
         if (p.W + 1 > c.pitch || p.W + 8 < c.pitch) continue;
         if (p.stride == 2 && 2 * (p.Wo - 1) - p.pad_l + 2 >= c.pitch) continue;
         if (band3_max_rows(c, p) < 1) continue;
@@ -319,9 +422,15 @@ int launch_band3_block(FusedBlockParams p, hipStream_t st) {
     if (p.B == 0) return SSD_OK;
     const int rmax = band3_max_rows(*c, p);
     p.bands = (p.Ho + rmax - 1) / rmax;
-    const size_t lds = band3_lds_bytes(*c, p);
+    size_t lds = band3_lds_bytes(*c, p);
     SSD_UNSUPPORTED_IF(lds > 160 * 1024, "band3 block: needs %zu B of LDS", lds);
-    const band3_kernel_t fn = p.bf16 ? c->fn1 : c->fn;
+    band3_kernel_t fn = p.bf16 ? c->fn1 : c->fn;
+    // second form: weight fragments through LDS (two We stages + one Wp stage of 1 KB blocks) where they fit
+    const size_t lds_d = lds + (size_t)(p.bf16 ? 1 : 3) * (2 + c->nt) * 1024;
+    if (p.form2 && lds_d <= 160 * 1024 && (p.bf16 ? c->fn1_d : c->fn_d)) {
+        fn = p.bf16 ? c->fn1_d : c->fn_d;
+        lds = lds_d;
+    }
     if (lds > 64 * 1024)
         SSD_HIP(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(fn, dim3((unsigned)((long)p.B * p.bands)), dim3(kB3Threads), lds, st, p);

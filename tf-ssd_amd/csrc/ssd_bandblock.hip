@@ -47,15 +47,18 @@ __device__ __forceinline__ void band_lds_barrier() { asm volatile("s_waitcnt lgk
 // tap of column 0 in band row 0) + every tile slot
 constexpr int band_ne(int T) { return 8 + T * 8 * 16; }
 
-template <int CIN, int NT, int T, int TO, int S, int P, bool DBG>
-__global__ __launch_bounds__(kBThreads) void mbv2_band_block_kernel(const FusedBlockParams p) {
+// WDMA (round 6, FusedBlockParams.form2): the fp32 weight fragments reach LDS by LDS-DMA (two stages each of the chunk's We rows
+// and Wp rows; 1 KB blocks of 16 rows x 16 floats, quad-swizzled through the per-lane source offset) instead of waiting in
+// registers one chunk ahead
+typedef __attribute__((address_space(3))) void* band_lds_dst_t;
+template <int CIN, int NT, int T, int TO, int S, int P, bool DBG, bool WDMA>
+__device__ __forceinline__ void band_body(const FusedBlockParams& p, char* __restrict__ smem) {
     static_assert(P % 8 == 0, "the dy tap offsets must keep the quad swizzle");
     constexpr int KC = CIN / 16;                  // 16-wide k blocks of the expand
     constexpr bool TAIL = (CIN % 16) == 8;        // + one 8-wide k tail (Cin = 24): 2 MFMA k-steps
     constexpr int NE = band_ne(T);
     constexpr int EBUF = NE * kBC * 4;            // bytes per E buffer
 
-    extern __shared__ __attribute__((aligned(16))) char smem[];
     char* Es = smem;                                             // [2][NE][16] floats, swizzled
     float* Ps = reinterpret_cast<float*>(smem + 2 * EBUF);       // [11][Ce]: expand shift, taps [9], depthwise shift
 
@@ -131,22 +134,58 @@ __global__ __launch_bounds__(kBThreads) void mbv2_band_block_kernel(const FusedB
         }
     }
 
-    // ---- A fragments of the weights, straight from global (L1 / L2 hits), one chunk ahead
+    // ---- A fragments of the weights: straight from global (L1 / L2 hits) one chunk ahead, or (WDMA) through LDS
+    constexpr int NBE = KC + (TAIL ? 1 : 0);      // 1 KB blocks of a We chunk (16 rows x 16 floats each)
+    float* Wes = Ps + 11 * p.Ce;                  // WDMA: [2][NBE] blocks of 256 floats
+    float* Wps = Wes + 2 * NBE * 256;             //       [2][NT] blocks
+    const int fslot = l15 * 16 + ((g4 ^ ((l15 >> 1) & 3)) * 4);                  // the lane's 16-byte slot inside a block
+    const int tslot = l15 * 16 + (((g4 >> 1) ^ ((l15 >> 1) & 3)) * 4) + (g4 & 1) * 2;   // ... its 8 bytes of the k tail
+    const int dr = lane >> 2, dq4 = ((lane & 3) ^ ((lane >> 3) & 3)) * 4;
+    const __amdgpu_buffer_rsrc_t rs_e = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.we), 0, (int)((long)p.Ce * p.kpad_e * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_p = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.wp), 0, (int)((long)p.npad_p * p.kpad_p * 4), 0x00020000);
+    const int voff_e = (dr * p.kpad_e + dq4) * 4, voff_p = (dr * p.kpad_p + dq4) * 4;
+    auto dma_we = [&](int j, int stage) {
+        for (int b = wave; b < NBE; b += 8)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_e, (band_lds_dst_t)(Wes + (stage * NBE + b) * 256), 16, voff_e,
+                                                     (int)(((long)j * kBC * p.kpad_e + b * 16) * 4), 0, 0);
+    };
+    auto dma_wp = [&](int j, int stage) {
+        for (int b = wave; b < NT; b += 8)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_p, (band_lds_dst_t)(Wps + (stage * NT + b) * 256), 16, voff_p,
+                                                     (int)(((long)b * 16 * p.kpad_p + j * kBC) * 4), 0, 0);
+    };
+    auto dma_wait = [&]() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); };
     f32x4 wa[KC], wan[KC], wp[NT], wpn[NT];
     f32x2 wat, watn;
     auto load_we = [&](f32x4 (&a)[KC], f32x2& at, int j) {
-        const float* wr = p.we + (long)(j * kBC + l15) * p.kpad_e;
+        if constexpr (WDMA) {
+            const float* wb = Wes + (j & 1) * NBE * 256;
 #pragma unroll
-        for (int kc = 0; kc < KC; ++kc) a[kc] = *reinterpret_cast<const f32x4*>(wr + kc * 16 + g4 * 4);
-        if (TAIL) at = *reinterpret_cast<const f32x2*>(wr + KC * 16 + g4 * 2);
+            for (int kc = 0; kc < KC; ++kc) a[kc] = *reinterpret_cast<const f32x4*>(wb + kc * 256 + fslot);
+            if (TAIL) at = *reinterpret_cast<const f32x2*>(wb + KC * 256 + tslot);
+        } else {
+            const float* wr = p.we + (long)(j * kBC + l15) * p.kpad_e;
+#pragma unroll
+            for (int kc = 0; kc < KC; ++kc) a[kc] = *reinterpret_cast<const f32x4*>(wr + kc * 16 + g4 * 4);
+            if (TAIL) at = *reinterpret_cast<const f32x2*>(wr + KC * 16 + g4 * 2);
+        }
     };
     auto load_wp = [&](f32x4 (&a)[NT], int j) {
 #pragma unroll
-        for (int ni = 0; ni < NT; ++ni)
-            a[ni] = *reinterpret_cast<const f32x4*>(p.wp + (long)(ni * 16 + l15) * p.kpad_p + j * kBC + g4 * 4);
+        for (int ni = 0; ni < NT; ++ni) {
+            if constexpr (WDMA) a[ni] = *reinterpret_cast<const f32x4*>(Wps + ((j & 1) * NT + ni) * 256 + fslot);
+            else a[ni] = *reinterpret_cast<const f32x4*>(p.wp + (long)(ni * 16 + l15) * p.kpad_p + j * kBC + g4 * 4);
+        }
     };
-    load_we(wa, wat, 0);
-    load_wp(wp, 0);
+    if constexpr (WDMA) {
+        dma_we(0, 0);
+        if (nchunk > 1) dma_we(1, 1);
+        dma_wp(0, 0);
+        dma_wait();
+    } else {
+        load_we(wa, wat, 0);
+        load_wp(wp, 0);
+    }
     __syncthreads();                              // Ps, zero rows
 
     auto expand = [&](int j, const f32x4 (&a)[KC], const f32x2 at) {
@@ -193,7 +232,6 @@ __global__ __launch_bounds__(kBThreads) void mbv2_band_block_kernel(const FusedB
 #pragma unroll
         for (int ni = 0; ni < NT; ++ni) acc[t][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    expand(0, wa, wat);
 
     // depthwise (this lane's pixel x 4 channels = the B fragment) + project MFMAs of chunk i, tile by tile.
     // Measured and not kept (each within the +-3 % run-to-run noise, at a cost in registers): requesting tile
@@ -232,6 +270,26 @@ __global__ __launch_bounds__(kBThreads) void mbv2_band_block_kernel(const FusedB
     // (Running { expand (i + 1), depthwise + project (i) } in the opposite order on waves 4-7, so that SIMD
     // partners are never in the same phase, was measured: +-3 %, no gain -- the kernel is issue bound, not
     // latency bound.)
+    if constexpr (WDMA) {
+        load_we(wa, wat, 0);
+        expand(0, wa, wat);
+        BTICK(0);
+        for (int i = 0; i < nchunk; ++i) {
+            dma_wait();                 // the copies of an iteration ago have landed ...
+            band_lds_barrier();         // ... and are visible; E(i) is complete; everyone is done reading E(i - 1)
+            BTICK(1);
+            if (i + 2 < nchunk) dma_we(i + 2, i & 1);           // the stage expand(i) read before this barrier
+            if (i + 1 < nchunk) dma_wp(i + 1, (i + 1) & 1);     // the stage dwproject(i - 1) read before this barrier
+            load_wp(wp, i);
+            dwproject(i, wp);
+            if (i + 1 < nchunk) {
+                load_we(wa, wat, i + 1);
+                expand(i + 1, wa, wat);
+            }
+            BTICK(4);
+        }
+    } else {
+    expand(0, wa, wat);
     if (nchunk > 1) load_we(wan, watn, 1);
     BTICK(0);
     for (int i = 0; i < nchunk; ++i) {
@@ -246,6 +304,8 @@ __global__ __launch_bounds__(kBThreads) void mbv2_band_block_kernel(const FusedB
             for (int ni = 0; ni < NT; ++ni) wp[ni] = wpn[ni];
         }
         BTICK(4);
+    }
+
     }
 
     // ---- epilogue: y = acc + shift (+ x); lane = 4 consecutive output channels of its pixel
@@ -269,12 +329,20 @@ __global__ __launch_bounds__(kBThreads) void mbv2_band_block_kernel(const FusedB
 #undef BTICK
 }
 
+template <int CIN, int NT, int T, int TO, int S, int P, bool DBG, bool WDMA = false>
+__global__ __launch_bounds__(kBThreads) void mbv2_band_block_kernel(const FusedBlockParams p) {
+    extern __shared__ __attribute__((aligned(1024))) char smem_band[];
+    band_body<CIN, NT, T, TO, S, P, DBG, WDMA>(p, smem_band);
+}
+
 typedef void (*band_kernel_t)(const FusedBlockParams);
 struct BandCfg {
     int cin, nt, t, to, stride, pitch;
     band_kernel_t fn, fn_dbg;       // fn_dbg: cycle counters + phase ablation (ssd_net_profile_fused)
+    band_kernel_t fn_d;             // weights staged by LDS-DMA (FusedBlockParams.form2)
 };
-#define BCFG(CIN, NT, T, TO, S, P) {CIN, NT, T, TO, S, P, mbv2_band_block_kernel<CIN, NT, T, TO, S, P, false>, mbv2_band_block_kernel<CIN, NT, T, TO, S, P, true>}
+#define BCFG(CIN, NT, T, TO, S, P) {CIN, NT, T, TO, S, P, mbv2_band_block_kernel<CIN, NT, T, TO, S, P, false>, mbv2_band_block_kernel<CIN, NT, T, TO, S, P, true>, \
+                                    mbv2_band_block_kernel<CIN, NT, T, TO, S, P, false, true>}
 const BandCfg kBand[] = {
     BCFG(16, 2, 9, 2, 2, 152),   // block 1: 16 -> 96 -> 24, 150x150 -> 75x75
     BCFG(24, 2, 8, 6, 1, 80),    // block 2: 24 -> 144 -> 24 (+x) at 75x75
@@ -343,10 +411,16 @@ int launch_band_block(FusedBlockParams p, hipStream_t st) {
     SSD_UNSUPPORTED_IF(lds > 160 * 1024, "band block: needs %zu B of LDS", lds);
     if (lds > 64 * 1024)
         SSD_HIP(hipFuncSetAttribute((const void*)c->fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    const band_kernel_t fn = (p.dbg || p.ablate) ? c->fn_dbg : c->fn;
-    if (lds > 64 * 1024 && fn != c->fn)
-        SSD_HIP(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(fn, dim3((unsigned)((long)p.B * p.bands)), dim3(kBThreads), lds, st, p);
+    band_kernel_t fn = (p.dbg || p.ablate) ? c->fn_dbg : c->fn;
+    size_t lds_use = lds;
+    const size_t lds_d = lds + (size_t)2 * (c->cin / 16 + ((c->cin % 16) == 8 ? 1 : 0) + c->nt) * 1024;     // + two stages of We and Wp blocks
+    if (p.form2 && fn == c->fn && lds_d <= 160 * 1024) {
+        fn = c->fn_d;
+        lds_use = lds_d;
+    }
+    if (lds_use > 64 * 1024 && fn != c->fn)
+        SSD_HIP(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_use));
+    hipLaunchKernelGGL(fn, dim3((unsigned)((long)p.B * p.bands)), dim3(kBThreads), lds_use, st, p);
     SSD_LAUNCH_CHECK();
     return SSD_OK;
 }

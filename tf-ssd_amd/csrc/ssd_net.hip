@@ -383,8 +383,8 @@ static FusedBlockParams fused_params(const ssd_net& net, const Layer& f, int B) 
         // (the in-launch ticketed combine exists for the fp32-MFMA form only: a no-op for the bf16 / split-bf16 forms)
         p.tickets = net.image_ticket && !p.bf16 ? net.img_tickets : nullptr;
         if (!p.bf16 && f.img_choice == 2) { p.bf16 = 3; p.tickets = nullptr; }    // the split-bf16 form of the image kernel (fp32 results)
-        p.form2 = net.image_v2 ? 1 : 0;
     }
+    p.form2 = net.image_v2 ? 1 : 0;          // second forms: whole-image kernel (ssd_imgblock2.hip), LDS-DMA weight staging of the split row-band kernel
     return p;
 }
 
