@@ -11,7 +11,7 @@ m.set_option("fuse_image", 2)
 data_utils.synthetic_weights(m)
 x = h.to_dev(data_utils.synthetic_images(B))
 m(x)
-for k in (7, 10):
+for k in [int(a) for a in sys.argv[2:]] or (7, 10):
     out = (ctypes.c_double * 6)()
     h.check(h.lib().ssd_net_profile_fused(m._net, ("block_%d_fused" % k).encode(), B, out), "profile_fused")
     print("block_%d: prologue own %.0f | prologue barrier wait %.0f | loop %.0f | epilogue %.0f  (shader clocks per wave, mean)" % (k, out[0], out[1], out[2], out[3]))
